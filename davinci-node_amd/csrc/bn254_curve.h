@@ -1,0 +1,125 @@
+// BN254 G1 / G2 group law for the MSM kernels: extended Jacobian (X, Y, ZZ, ZZZ) buckets + affine points.
+//
+// Stands in for gnark-crypto's g1JacExtended / g2JacExtended bucket arithmetic inside G1Jac.MultiExp /
+// G2Jac.MultiExp (reached from /root/reference/prover/prover_cpu.go:37).
+// Formulas: EFD madd-2008-s, add-2008-s, dbl-2008-s-1, mdbl-2008-s-1 (a = 0).  Affine infinity is (0,0)
+// (row a15); a bucket at infinity has ZZ == literal 0.
+#pragma once
+#include "bn254_field.h"
+
+namespace dvn {
+
+template <class F> struct Affine { F x, y; };
+template <class F> struct Xyzz { F x, y, zz, zzz; };
+
+template <class F> struct Curve {
+    typedef Ops<F> O;
+    typedef Affine<F> A;
+    typedef Xyzz<F> X;
+
+    static DVN_HD X infinity() { return X{O::one(), O::one(), O::zero(), O::zero()}; }
+    static DVN_HD bool is_inf(const X& p) { return O::is_literal_zero(p.zz); }
+    static DVN_HD bool is_inf(const A& p) { return O::is_literal_zero(p.x) && O::is_literal_zero(p.y); }
+    static DVN_HD X from_affine(const A& p) { return is_inf(p) ? infinity() : X{p.x, p.y, O::one(), O::one()}; }
+    static DVN_HD A neg(const A& p) { return A{p.x, O::neg(p.y)}; }
+    static DVN_HD X neg(const X& p) { return X{p.x, O::neg(p.y), p.zz, p.zzz}; }
+
+    // 2*q for affine q != infinity (mdbl-2008-s-1)
+    static DVN_HD X dbl_affine(const A& q) {
+        F U = O::dbl(q.y), V = O::sqr(U), W = O::mul(U, V), S = O::mul(q.x, V);
+        F xx = O::sqr(q.x), M = O::add(O::dbl(xx), xx);
+        F X3 = O::sub(O::sub(O::sqr(M), S), S);
+        F Y3 = O::sub(O::mul(M, O::sub(S, X3)), O::mul(W, q.y));
+        return X{X3, Y3, V, W};
+    }
+    // 2*p (dbl-2008-s-1)
+    static DVN_HD X dbl(const X& p) {
+        if (is_inf(p)) return p;
+        F U = O::dbl(p.y), V = O::sqr(U), W = O::mul(U, V), S = O::mul(p.x, V);
+        F xx = O::sqr(p.x), M = O::add(O::dbl(xx), xx);
+        F X3 = O::sub(O::sub(O::sqr(M), S), S);
+        F Y3 = O::sub(O::mul(M, O::sub(S, X3)), O::mul(W, p.y));
+        return X{X3, Y3, O::mul(V, p.zz), O::mul(W, p.zzz)};
+    }
+    // p + q, q affine (madd-2008-s); q may be infinity
+    static DVN_HD X add_mixed(const X& p, const A& q) {
+        if (is_inf(q)) return p;
+        if (is_inf(p)) return X{q.x, q.y, O::one(), O::one()};
+        F U2 = O::mul(q.x, p.zz), S2 = O::mul(q.y, p.zzz);
+        F P = O::sub(U2, p.x), R = O::sub(S2, p.y);
+        if (O::is_zero(P)) {
+            if (O::is_zero(R)) return dbl_affine(q);
+            return infinity();
+        }
+        F PP = O::sqr(P), PPP = O::mul(P, PP), Q = O::mul(p.x, PP);
+        F X3 = O::sub(O::sub(O::sub(O::sqr(R), PPP), Q), Q);
+        F Y3 = O::sub(O::mul(R, O::sub(Q, X3)), O::mul(p.y, PPP));
+        return X{X3, Y3, O::mul(p.zz, PP), O::mul(p.zzz, PPP)};
+    }
+    // p + q (add-2008-s)
+    static DVN_HD X add(const X& p, const X& q) {
+        if (is_inf(q)) return p;
+        if (is_inf(p)) return q;
+        F U1 = O::mul(p.x, q.zz), U2 = O::mul(q.x, p.zz);
+        F S1 = O::mul(p.y, q.zzz), S2 = O::mul(q.y, p.zzz);
+        F P = O::sub(U2, U1), R = O::sub(S2, S1);
+        if (O::is_zero(P)) {
+            if (O::is_zero(R)) return dbl(p);
+            return infinity();
+        }
+        F PP = O::sqr(P), PPP = O::mul(P, PP), Q = O::mul(U1, PP);
+        F X3 = O::sub(O::sub(O::sub(O::sqr(R), PPP), Q), Q);
+        F Y3 = O::sub(O::mul(R, O::sub(Q, X3)), O::mul(S1, PPP));
+        return X{X3, Y3, O::mul(O::mul(p.zz, q.zz), PP), O::mul(O::mul(p.zzz, q.zzz), PPP)};
+    }
+    // [k]p for a small non-negative integer k (MSB-first double-and-add)
+    static DVN_HD X mul_small(const X& p, u32 k) {
+        X acc = infinity();
+        for (int i = 31; i >= 0; --i) {
+            acc = dbl(acc);
+            if ((k >> i) & 1) acc = add(acc, p);
+        }
+        return acc;
+    }
+    static DVN_HD A to_affine(const X& p) {
+        if (is_inf(p)) return A{O::zero(), O::zero()};
+        F zi = O::inv(p.zzz);                       // 1/ZZZ
+        F iz2 = O::sqr(O::mul(zi, p.zz));           // (ZZ/ZZZ)^2 = 1/ZZ
+        return A{O::mul(p.x, iz2), O::mul(p.y, zi)};
+    }
+
+    // ---- memory images ----------------------------------------------------------------------------------
+    // Device-resident points/buckets are stored in *internal* Montgomery form (R' = 2^261) packed as
+    // 8 x u32 per Fp coordinate, so a load is pure bit slicing.  AW / XW = u32 words per affine / xyzz.
+    static constexpr int AW = 2 * O::WORDS;
+    static constexpr int XW = 4 * O::WORDS;
+    static DVN_HD A load_affine_internal(const u32* w) { return A{O::load_internal(w), O::load_internal(w + O::WORDS)}; }
+    static DVN_HD void store_affine_internal(const A& p, u32* w) { O::store_internal(p.x, w); O::store_internal(p.y, w + O::WORDS); }
+    static DVN_HD X load_xyzz_internal(const u32* w) {
+        return X{O::load_internal(w), O::load_internal(w + O::WORDS), O::load_internal(w + 2 * O::WORDS), O::load_internal(w + 3 * O::WORDS)};
+    }
+    static DVN_HD void store_xyzz_internal(const X& p, u32* w) {
+        if (is_inf(p)) {          // canonical image of infinity: all-zero ZZ/ZZZ (X, Y arbitrary -> 0)
+            for (int i = 0; i < XW; ++i) w[i] = 0;
+            return;
+        }
+        O::store_internal(p.x, w); O::store_internal(p.y, w + O::WORDS);
+        O::store_internal(p.zz, w + 2 * O::WORDS); O::store_internal(p.zzz, w + 3 * O::WORDS);
+    }
+    // gnark affine image (Montgomery R = 2^256) <-> internal
+    static DVN_HD A affine_from_ext(const u32* w) {
+        bool z = true;
+        for (int i = 0; i < AW; ++i) z = z && (w[i] == 0);
+        if (z) return A{O::zero(), O::zero()};
+        return A{O::from_ext(w), O::from_ext(w + O::WORDS)};
+    }
+    static DVN_HD void affine_to_ext(const A& p, u32* w) {
+        if (is_inf(p)) { for (int i = 0; i < AW; ++i) w[i] = 0; return; }
+        O::to_ext(p.x, w); O::to_ext(p.y, w + O::WORDS);
+    }
+};
+
+typedef Curve<Fp> G1;
+typedef Curve<Fp2> G2;
+
+}  // namespace dvn
