@@ -1,0 +1,246 @@
+"""ctypes binding of include/dvn_prover.h.  Thin: argument marshalling and error mapping only."""
+from __future__ import annotations
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+DIF, DIT = 0, 1
+MSM_SCALARS_ON_DEVICE = 1
+NTT_DATA_ON_DEVICE = 1
+
+_U64P = C.POINTER(C.c_uint64)
+
+
+class DvnError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"dvn error {code}: {msg}")
+        self.code = code
+
+
+def lib_path() -> str:
+    return os.path.join(_CSRC, "libdvn_prover.so")
+
+
+def build_library(jobs: int = 4) -> str:
+    """Compile every HIP translation unit for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-C", _CSRC, f"-j{jobs}", "-s", "all"])
+    return lib_path()
+
+
+_lib = None
+
+
+def load_library():
+    """Load libdvn_prover.so.  Fails loudly if it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise FileNotFoundError(f"{p} not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+    L = C.CDLL(p)
+    vp, sz, u32, i32, u64 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int32, C.c_uint64
+    sig = {
+        "dvn_init": (i32, [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]),
+        "dvn_shutdown": (None, [vp]),
+        "dvn_last_error": (C.c_char_p, [vp]),
+        "dvn_version": (C.c_char_p, []),
+        "dvn_malloc": (i32, [vp, sz, C.POINTER(vp)]),
+        "dvn_free": (i32, [vp, vp]),
+        "dvn_memcpy_h2d": (i32, [vp, vp, vp, sz]),
+        "dvn_memcpy_d2h": (i32, [vp, vp, vp, sz]),
+        "dvn_synchronize": (i32, [vp]),
+        "dvn_points_upload_g1": (i32, [vp, vp, sz, C.POINTER(vp)]),
+        "dvn_points_upload_g2": (i32, [vp, vp, sz, C.POINTER(vp)]),
+        "dvn_points_synthetic_g1": (i32, [vp, u64, sz, C.POINTER(vp)]),
+        "dvn_points_synthetic_g2": (i32, [vp, u64, sz, C.POINTER(vp)]),
+        "dvn_points_download": (i32, [vp, vp, sz, sz, vp]),
+        "dvn_points_len": (sz, [vp]),
+        "dvn_points_free": (i32, [vp, vp]),
+        "dvn_msm_g1": (i32, [vp, vp, sz, sz, vp, u32, vp]),
+        "dvn_msm_g2": (i32, [vp, vp, sz, sz, vp, u32, vp]),
+        "dvn_msm_plan": (i32, [sz, C.POINTER(u32), C.POINTER(u32)]),
+        "dvn_msm_g1_windows": (i32, [vp, vp, sz, sz, vp, u32, u32, u32, vp]),
+        "dvn_msm_combine_g1": (i32, [vp, vp, u32, u32, vp]),
+        "dvn_ntt_domain": (i32, [vp, u32, C.POINTER(vp)]),
+        "dvn_ntt_domain_free": (i32, [vp, vp]),
+        "dvn_ntt": (i32, [vp, vp, vp, C.c_int, C.c_int, C.c_int, u32]),
+        "dvn_groth16_compute_h": (i32, [vp, vp, vp, vp, vp, sz, vp, u32]),
+        "dvn_last_kernel_ms": (i32, [vp, C.c_int, C.POINTER(C.c_float)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)           # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = [
+    "dvn_init", "dvn_shutdown", "dvn_last_error", "dvn_version", "dvn_malloc", "dvn_free", "dvn_memcpy_h2d",
+    "dvn_memcpy_d2h", "dvn_synchronize", "dvn_points_upload_g1", "dvn_points_upload_g2", "dvn_points_synthetic_g1",
+    "dvn_points_synthetic_g2", "dvn_points_download", "dvn_points_len", "dvn_points_free", "dvn_msm_g1", "dvn_msm_g2",
+    "dvn_msm_plan", "dvn_msm_g1_windows", "dvn_msm_combine_g1", "dvn_ntt_domain", "dvn_ntt_domain_free", "dvn_ntt",
+    "dvn_groth16_compute_h", "dvn_last_kernel_ms",
+]
+
+
+def _host(a: np.ndarray) -> C.c_void_p:
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"], "expect C-contiguous uint64"
+    return C.c_void_p(a.ctypes.data)
+
+
+class Points:
+    def __init__(self, ctx: "Context", handle, curve: int):
+        self.ctx, self.handle, self.curve = ctx, handle, curve
+
+    def __len__(self):
+        return int(self.ctx.L.dvn_points_len(self.handle))
+
+    def download(self, off: int = 0, n: int | None = None) -> np.ndarray:
+        n = len(self) - off if n is None else n
+        out = np.zeros((n, 8 if self.curve == 1 else 16), dtype=np.uint64)
+        self.ctx._chk(self.ctx.L.dvn_points_download(self.ctx.h, self.handle, off, n, _host(out)))
+        return out
+
+    def free(self):
+        if self.handle:
+            self.ctx._chk(self.ctx.L.dvn_points_free(self.ctx.h, self.handle))
+            self.handle = None
+
+
+class Domain:
+    def __init__(self, ctx: "Context", handle, log_n: int):
+        self.ctx, self.handle, self.log_n = ctx, handle, log_n
+
+    @property
+    def n(self):
+        return 1 << self.log_n
+
+    def free(self):
+        if self.handle:
+            self.ctx._chk(self.ctx.L.dvn_ntt_domain_free(self.ctx.h, self.handle))
+            self.handle = None
+
+
+class Context:
+    """One context per process-GPU (dvn_init).  Raises DvnError on any failure; never falls back to a CPU path."""
+
+    def __init__(self, device: int = 0):
+        self.L = load_library()
+        h = C.c_void_p()
+        devs = (C.c_int * 1)(device)
+        rc = self.L.dvn_init(devs, 1, C.byref(h))
+        if rc != 0:
+            raise DvnError(rc, self.L.dvn_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.dvn_shutdown(self.h)
+            self.h = None
+
+    def _chk(self, rc: int):
+        if rc != 0:
+            raise DvnError(rc, self.L.dvn_last_error(self.h).decode())
+
+    # ---- memory
+    def malloc(self, nbytes: int) -> int:
+        p = C.c_void_p(); self._chk(self.L.dvn_malloc(self.h, nbytes, C.byref(p))); return p.value
+
+    def free(self, dptr: int):
+        self._chk(self.L.dvn_free(self.h, C.c_void_p(dptr)))
+
+    def h2d(self, dptr: int, a: np.ndarray):
+        self._chk(self.L.dvn_memcpy_h2d(self.h, C.c_void_p(dptr), C.c_void_p(a.ctypes.data), a.nbytes))
+
+    def d2h(self, a: np.ndarray, dptr: int):
+        self._chk(self.L.dvn_memcpy_d2h(self.h, C.c_void_p(a.ctypes.data), C.c_void_p(dptr), a.nbytes))
+
+    def to_device(self, a: np.ndarray) -> int:
+        a = np.ascontiguousarray(a); p = self.malloc(a.nbytes); self.h2d(p, a); return p
+
+    def synchronize(self):
+        self._chk(self.L.dvn_synchronize(self.h))
+
+    # ---- points
+    def upload_g1(self, xy: np.ndarray) -> Points:
+        xy = np.ascontiguousarray(xy, dtype=np.uint64).reshape(-1, 8)
+        p = C.c_void_p(); self._chk(self.L.dvn_points_upload_g1(self.h, _host(xy), xy.shape[0], C.byref(p))); return Points(self, p, 1)
+
+    def upload_g2(self, xy: np.ndarray) -> Points:
+        xy = np.ascontiguousarray(xy, dtype=np.uint64).reshape(-1, 16)
+        p = C.c_void_p(); self._chk(self.L.dvn_points_upload_g2(self.h, _host(xy), xy.shape[0], C.byref(p))); return Points(self, p, 2)
+
+    def synthetic_g1(self, seed: int, n: int) -> Points:
+        p = C.c_void_p(); self._chk(self.L.dvn_points_synthetic_g1(self.h, seed, n, C.byref(p))); return Points(self, p, 1)
+
+    def synthetic_g2(self, seed: int, n: int) -> Points:
+        p = C.c_void_p(); self._chk(self.L.dvn_points_synthetic_g2(self.h, seed, n, C.byref(p))); return Points(self, p, 2)
+
+    # ---- MSM.  scalars: (n,4) uint64 host array, or an int device pointer with n given.
+    def _scalars(self, scalars, n):
+        if isinstance(scalars, (int, np.integer)):
+            assert n is not None
+            return C.c_void_p(int(scalars)), n, MSM_SCALARS_ON_DEVICE
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        self._keep = scalars
+        return _host(scalars), scalars.shape[0], 0
+
+    def msm_g1(self, pts: Points, scalars, off: int = 0, n: int | None = None) -> np.ndarray:
+        """Returns the G1Jac image (12 uint64).  n defaults to len(scalars); MultiExp's length rule is checked by the library."""
+        sp, ns, fl = self._scalars(scalars, n)
+        out = np.zeros(12, dtype=np.uint64)
+        self._chk(self.L.dvn_msm_g1(self.h, pts.handle, off, ns, sp, fl, _host(out)))
+        return out
+
+    def msm_g2(self, pts: Points, scalars, off: int = 0, n: int | None = None) -> np.ndarray:
+        sp, ns, fl = self._scalars(scalars, n)
+        out = np.zeros(24, dtype=np.uint64)
+        self._chk(self.L.dvn_msm_g2(self.h, pts.handle, off, ns, sp, fl, _host(out)))
+        return out
+
+    def msm_plan(self, n: int):
+        c, w = C.c_uint32(), C.c_uint32()
+        rc = self.L.dvn_msm_plan(n, C.byref(c), C.byref(w))
+        self._chk(rc)
+        return c.value, w.value
+
+    def msm_g1_windows(self, pts: Points, scalars, win_lo: int, win_hi: int, off: int = 0, n: int | None = None) -> np.ndarray:
+        sp, ns, fl = self._scalars(scalars, n)
+        out = np.zeros((win_hi - win_lo, 16), dtype=np.uint64)
+        self._chk(self.L.dvn_msm_g1_windows(self.h, pts.handle, off, ns, sp, fl, win_lo, win_hi, _host(out)))
+        return out
+
+    def msm_combine_g1(self, window_sums: np.ndarray, window_bits: int) -> np.ndarray:
+        ws = np.ascontiguousarray(window_sums, dtype=np.uint64).reshape(-1, 16)
+        out = np.zeros(12, dtype=np.uint64)
+        self._chk(self.L.dvn_msm_combine_g1(self.h, _host(ws), ws.shape[0], window_bits, _host(out)))
+        return out
+
+    # ---- NTT
+    def domain(self, log_n: int) -> Domain:
+        p = C.c_void_p(); self._chk(self.L.dvn_ntt_domain(self.h, log_n, C.byref(p))); return Domain(self, p, log_n)
+
+    def ntt(self, dom: Domain, data, inverse: bool, decimation: int, coset: bool = False):
+        """In place.  data: (n,4) uint64 host array (modified) or int device pointer."""
+        if isinstance(data, (int, np.integer)):
+            self._chk(self.L.dvn_ntt(self.h, dom.handle, C.c_void_p(int(data)), int(inverse), decimation, int(coset), NTT_DATA_ON_DEVICE))
+            return data
+        assert data.dtype == np.uint64 and data.flags["C_CONTIGUOUS"] and data.shape == (dom.n, 4)
+        self._chk(self.L.dvn_ntt(self.h, dom.handle, _host(data), int(inverse), decimation, int(coset), 0))
+        return data
+
+    def compute_h(self, dom: Domain, a: np.ndarray, b: np.ndarray, c: np.ndarray) -> np.ndarray:
+        a, b, c = (np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4) for v in (a, b, c))
+        if not (a.shape == b.shape == c.shape):
+            raise ValueError("a, b, c must have the same length")
+        out = np.zeros((dom.n, 4), dtype=np.uint64)
+        self._chk(self.L.dvn_groth16_compute_h(self.h, dom.handle, _host(a), _host(b), _host(c), a.shape[0], _host(out), 0))
+        return out
+
+    def last_kernel_ms(self, which: int = 0) -> float:
+        ms = C.c_float(); self._chk(self.L.dvn_last_kernel_ms(self.h, which, C.byref(ms))); return float(ms.value)

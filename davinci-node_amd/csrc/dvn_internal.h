@@ -1,0 +1,131 @@
+// Internal declarations shared by the translation units of libdvn_prover.so (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/dvn_prover.h"
+#include "bn254_curve.h"
+
+using namespace dvn;
+
+// ------------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------------
+extern thread_local std::string tl_error;
+
+struct dvn_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // 0/1: whole device section, 2/3: dominant kernel
+    float last_ms[2] = {0.f, 0.f};
+    void* ws = nullptr;       // grow-only workspace
+    size_t ws_bytes = 0;
+    std::mutex mu;
+    bool force_fail = false;
+};
+struct dvn_points {
+    int curve = 1;            // 1 = G1, 2 = G2
+    size_t n = 0;
+    u32* d = nullptr;         // internal affine image, n * AW words
+};
+struct dvn_domain {
+    u32 log_n = 0;
+    u32* tw_fwd = nullptr;    // per-stage tables, n-1 entries (8 words each), entry (n - (n>>s)) + k = w^(k<<s)
+    u32* tw_inv = nullptr;
+    // coset power tables (exponent split lo/hi), internal form
+    u32 lo_bits = 0;
+    u32 *g_lo = nullptr, *g_hi = nullptr;            // g^j, g^(j<<lo_bits)
+    u32 *gi_lo = nullptr, *gi_hi = nullptr;          // g^-j / n, g^-(j<<lo_bits)
+    u32* card_inv = nullptr;                         // 1/n (one element)
+    u32* h_consts = nullptr;                         // k1 = den*2^5, k2 = den (computeH)
+};
+
+int32_t fail(int32_t code, const char* fmt, ...);
+#define HIP_TRY(expr)                                                                                         \
+    do {                                                                                                      \
+        hipError_t _e = (expr);                                                                               \
+        if (_e != hipSuccess) {                                                                               \
+            int32_t code = (_e == hipErrorOutOfMemory) ? DVN_ERR_OOM : DVN_ERR_DEVICE;                        \
+            (void)hipGetLastError();                                                                          \
+            return fail(code, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);      \
+        }                                                                                                     \
+    } while (0)
+#define TRY(expr) do { int32_t _rc = (expr); if (_rc != DVN_OK) return _rc; } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static inline int32_t enter(dvn_ctx* ctx) {
+    if (!ctx) return fail(DVN_ERR_INVALID_ARG, "ctx is NULL");
+    if (ctx->force_fail) return fail(DVN_ERR_INJECTED, "DVN_FORCE_FAIL is set: injected device failure");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return DVN_OK;
+}
+static inline int32_t ensure_ws(dvn_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->ws_bytes) return DVN_OK;
+    if (ctx->ws) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(ctx->ws)); ctx->ws = nullptr; ctx->ws_bytes = 0; }
+    size_t want = align_up(bytes + bytes / 8, 1 << 20);
+    HIP_TRY(hipMalloc(&ctx->ws, want));
+    ctx->ws_bytes = want;
+    return DVN_OK;
+}
+struct Carver {
+    char* base; size_t off = 0;
+    explicit Carver(void* b) : base((char*)b) {}
+    template <class T> T* take(size_t count) { off = align_up(off, 256); T* p = (T*)(base + off); off += count * sizeof(T); return p; }
+};
+struct CarverSize {
+    size_t off = 0;
+    void take(size_t bytes) { off = align_up(off, 256); off += bytes; }
+};
+
+// ------------------------------------------------------------------------------------------------------
+// host helpers on the shared arithmetic headers
+// ------------------------------------------------------------------------------------------------------
+static inline u64 splitmix_at(u64 seed, u64 index) {
+    u64 z = seed + (index + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+static const u32 FR_MOD_W[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+static inline bool geq8(const u32* a, const u32* b) {
+    for (int i = 7; i >= 0; --i) { if (a[i] > b[i]) return true; if (a[i] < b[i]) return false; }
+    return true;
+}
+static inline void sub8(u32* a, const u32* b) {
+    u64 br = 0;
+    for (int i = 0; i < 8; ++i) { u64 d = (u64)a[i] - b[i] - br; a[i] = (u32)d; br = (d >> 32) & 1; }
+}
+// i-th canonical Fr of SplitMix64 stream `seed` (oracle/bn254_py.py fr_at)
+static inline void fr_at_words(u64 seed, u64 i, u32 out[8]) {
+    for (int k = 0; k < 4; ++k) { u64 v = splitmix_at(seed, 4 * i + k); out[2 * k] = (u32)v; out[2 * k + 1] = (u32)(v >> 32); }
+    while (geq8(out, FR_MOD_W)) sub8(out, FR_MOD_W);
+}
+template <class Cv> static inline typename Cv::X host_scalar_mul(const typename Cv::A& p, const u32 k[8]) {
+    typename Cv::X acc = Cv::infinity();
+    for (int b = 255; b >= 0; --b) {
+        acc = Cv::dbl(acc);
+        if ((k[b >> 5] >> (b & 31)) & 1) acc = Cv::add_mixed(acc, p);
+    }
+    return acc;
+}
+static inline G1::A g1_generator() {
+    u32 one[8] = {1, 0, 0, 0, 0, 0, 0, 0}, two[8] = {2, 0, 0, 0, 0, 0, 0, 0};
+    return G1::A{fe_from_canonical<FpCfg>(fe_unpack<FpCfg>(one)), fe_from_canonical<FpCfg>(fe_unpack<FpCfg>(two))};
+}
+static inline G2::A g2_generator() {   // EIP-197 generator, gnark Montgomery image (oracle/bn254_cpu.c G2_GEN_MONT)
+    static const u64 g[16] = {
+        0x8e83b5d102bc2026ULL, 0xdceb1935497b0172ULL, 0xfbb8264797811adfULL, 0x19573841af96503bULL,
+        0xafb4737da84c6140ULL, 0x6043dd5a5802d8c4ULL, 0x09e950fc52a02f86ULL, 0x14fef0833aea7b6bULL,
+        0x619dfa9d886be9f6ULL, 0xfe7fd297f59e9b78ULL, 0xff9e1a62231b7dfeULL, 0x28fd7eebae9e4206ULL,
+        0x64095b56c71856eeULL, 0xdc57f922327d3cbbULL, 0x55f935be33351076ULL, 0x0da4a0e693fd6482ULL};
+    return G2::affine_from_ext((const u32*)g);
+}
+

@@ -1,0 +1,78 @@
+// G1 instantiation of the MSM pipeline + curve-independent point-set entry points.
+#include "msm_driver.h"
+
+int32_t dvn_internal_points_download_g2(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, uint64_t* xy);   // dvn_msm_g2.hip
+
+extern "C" int32_t dvn_points_upload_g1(dvn_ctx* ctx, const uint64_t* xy, size_t n, dvn_points** out) { return points_upload<G1>(ctx, xy, n, 1, out); }
+
+extern "C" int32_t dvn_points_synthetic_g1(dvn_ctx* ctx, uint64_t seed, size_t n, dvn_points** out) { return points_synthetic<G1>(ctx, seed, n, 1, g1_generator(), out); }
+
+extern "C" int32_t dvn_msm_g1(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags, uint64_t out_jac[12]) {
+    return msm_full<G1>(ctx, pts, 1, off, n, scalars, flags, out_jac);
+}
+
+extern "C" int32_t dvn_msm_g1_windows(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
+                                      uint32_t win_lo, uint32_t win_hi, uint64_t* window_sums) {
+    TRY(enter(ctx));
+    if (!pts || !window_sums || (!scalars && n)) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    if (pts->curve != 1) return fail(DVN_ERR_INVALID_ARG, "point set is not G1");
+    if (off > pts->n || n > pts->n - off) return fail(DVN_ERR_INVALID_ARG, "len(points) != len(scalars)");
+    u32 c, nwin; msm_plan(n, &c, &nwin);
+    if (win_lo > win_hi || win_hi > nwin) return fail(DVN_ERR_INVALID_ARG, "window range [%u, %u) outside [0, %u)", win_lo, win_hi, nwin);
+    const u32 W = win_hi - win_lo;
+    if (W == 0) return DVN_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::vector<u32> sums((size_t)W * G1::XW, 0u);
+    if (n) TRY(msm_windows<G1>(ctx, pts, off, n, scalars, flags, c, nwin, win_lo, win_hi, sums.data()));
+    // export as external-Montgomery (X, Y, ZZ, ZZZ); infinity = all zero
+    u32* o = (u32*)window_sums;
+    for (u32 w = 0; w < W; ++w) {
+        G1::X p = G1::load_xyzz_internal(sums.data() + (size_t)w * G1::XW);
+        if (G1::is_inf(p)) { memset(o + (size_t)w * 32, 0, 128); continue; }
+        Ops<Fp>::to_ext(p.x, o + w * 32); Ops<Fp>::to_ext(p.y, o + w * 32 + 8);
+        Ops<Fp>::to_ext(p.zz, o + w * 32 + 16); Ops<Fp>::to_ext(p.zzz, o + w * 32 + 24);
+    }
+    return DVN_OK;
+}
+
+extern "C" int32_t dvn_msm_combine_g1(dvn_ctx* ctx, const uint64_t* window_sums, uint32_t nwin, uint32_t window_bits, uint64_t out_jac[12]) {
+    if (!ctx || !window_sums || !out_jac) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    if (window_bits == 0 || window_bits > 16 || nwin == 0 || nwin > 64) return fail(DVN_ERR_INVALID_ARG, "bad window layout");
+    const u32* in = (const u32*)window_sums;
+    std::vector<u32> sums((size_t)nwin * G1::XW);
+    for (u32 w = 0; w < nwin; ++w) {
+        bool z = true;
+        for (int i = 16; i < 24; ++i) z = z && in[w * 32 + i] == 0;
+        G1::X p = z ? G1::infinity()
+                    : G1::X{Ops<Fp>::from_ext(in + w * 32), Ops<Fp>::from_ext(in + w * 32 + 8), Ops<Fp>::from_ext(in + w * 32 + 16), Ops<Fp>::from_ext(in + w * 32 + 24)};
+        G1::store_xyzz_internal(p, sums.data() + (size_t)w * G1::XW);
+    }
+    write_jac<G1>(horner<G1>(sums.data(), nwin, window_bits), out_jac);
+    return DVN_OK;
+}
+
+extern "C" size_t dvn_points_len(const dvn_points* pts) { return pts ? pts->n : 0; }
+
+extern "C" int32_t dvn_points_free(dvn_ctx* ctx, dvn_points* pts) {
+    TRY(enter(ctx));
+    if (!pts) return DVN_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (pts->d) HIP_TRY(hipFree(pts->d));
+    delete pts;
+    return DVN_OK;
+}
+
+extern "C" int32_t dvn_points_download(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, uint64_t* xy) {
+    TRY(enter(ctx));
+    if (!pts || (!xy && n)) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    if (off > pts->n || n > pts->n - off) return fail(DVN_ERR_INVALID_ARG, "range [%zu, %zu) outside point set of %zu", off, off + n, pts->n);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return pts->curve == 1 ? points_download<G1>(ctx, pts, off, n, xy) : dvn_internal_points_download_g2(ctx, pts, off, n, xy);
+}
+
+extern "C" int32_t dvn_msm_plan(size_t n, uint32_t* window_bits, uint32_t* nwin) {
+    if (!window_bits || !nwin) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    msm_plan(n, window_bits, nwin);
+    return DVN_OK;
+}

@@ -1,0 +1,195 @@
+// Host drivers of the MSM pipeline, templated on the curve; included by dvn_msm_g1.hip / dvn_msm_g2.hip so the
+// two instantiations compile in parallel.
+#pragma once
+#include "dvn_internal.h"
+#include "msm_kernels.h"
+
+// ------------------------------------------------------------------------------------------------------
+// points
+// ------------------------------------------------------------------------------------------------------
+template <class Cv> static int32_t points_upload(dvn_ctx* ctx, const uint64_t* xy, size_t n, int curve, dvn_points** out) {
+    TRY(enter(ctx));
+    if (!out || (!xy && n)) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    if (n >= (1ull << 31)) return fail(DVN_ERR_INVALID_ARG, "point set too large (n must be < 2^31)");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    dvn_points* p = new (std::nothrow) dvn_points();
+    if (!p) return fail(DVN_ERR_OOM, "host allocation failed");
+    p->curve = curve; p->n = n;
+    size_t bytes = n * Cv::AW * 4;
+    hipError_t e = hipMalloc((void**)&p->d, bytes ? bytes : 16);
+    if (e != hipSuccess) { delete p; (void)hipGetLastError(); return fail(DVN_ERR_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+    if (n) {
+        e = hipMemcpyAsync(p->d, xy, bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            k_points_to_internal<Cv><<<(unsigned)((n + 127) / 128), 128, 0, ctx->stream>>>(p->d, n);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // caller's buffer is free after return
+        if (e != hipSuccess) { (void)hipFree(p->d); delete p; (void)hipGetLastError(); return fail(DVN_ERR_DEVICE, "point upload failed: %s", hipGetErrorString(e)); }
+    }
+    *out = p;
+    return DVN_OK;
+}
+
+template <class Cv> static int32_t points_synthetic(dvn_ctx* ctx, uint64_t seed, size_t n, int curve, const typename Cv::A& gen, dvn_points** out) {
+    TRY(enter(ctx));
+    if (!out) return fail(DVN_ERR_INVALID_ARG, "out is NULL");
+    if (n >= (1ull << 31)) return fail(DVN_ERR_INVALID_ARG, "point set too large");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    u32 s0[8], s1[8]; fr_at_words(seed, 0, s0); fr_at_words(seed, 1, s1);
+    typename Cv::A base = Cv::to_affine(host_scalar_mul<Cv>(gen, s0)), step = Cv::to_affine(host_scalar_mul<Cv>(gen, s1));
+    u32 hb[2 * Cv::AW];
+    Cv::store_affine_internal(base, hb); Cv::store_affine_internal(step, hb + Cv::AW);
+    dvn_points* p = new (std::nothrow) dvn_points();
+    if (!p) return fail(DVN_ERR_OOM, "host allocation failed");
+    p->curve = curve; p->n = n;
+    u32* dbs = nullptr;
+    hipError_t e = hipMalloc((void**)&p->d, n ? n * Cv::AW * 4 : 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&dbs, sizeof(hb));
+    if (e == hipSuccess) e = hipMemcpyAsync(dbs, hb, sizeof(hb), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && n) {
+        const u32 chunk = 16;
+        size_t threads = (n + chunk - 1) / chunk;
+        k_points_progression<Cv><<<(unsigned)((threads + 63) / 64), 64, 0, ctx->stream>>>(p->d, n, dbs, chunk);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (dbs) (void)hipFree(dbs);
+    if (e != hipSuccess) { if (p->d) (void)hipFree(p->d); delete p; (void)hipGetLastError(); return fail(DVN_ERR_DEVICE, "synthetic points failed: %s", hipGetErrorString(e)); }
+    *out = p;
+    return DVN_OK;
+}
+
+template <class Cv> static int32_t points_download(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, uint64_t* xy) {
+    if (n == 0) return DVN_OK;
+    u32* tmp = nullptr;
+    HIP_TRY(hipMalloc((void**)&tmp, n * Cv::AW * 4));
+    k_points_to_external<Cv><<<(unsigned)((n + 127) / 128), 128, 0, ctx->stream>>>(pts->d + off * Cv::AW, tmp, n);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(xy, tmp, n * Cv::AW * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(DVN_ERR_DEVICE, "point download failed: %s", hipGetErrorString(e)); }
+    return DVN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// MSM
+// ------------------------------------------------------------------------------------------------------
+static void msm_plan(size_t n, u32* c_out, u32* nwin_out) {
+    // minimise nwin * (n + 3 * 2^(c-1)): n mixed additions per window plus ~3 additions per bucket to reduce
+    u32 best = 8; double bc = 1e300;
+    for (u32 c = 6; c <= 16; ++c) {
+        double cost = (double)(254 / c + 1) * ((double)n + 3.0 * (double)(1u << (c - 1)));
+        if (cost < bc) { bc = cost; best = c; }
+    }
+    *c_out = best; *nwin_out = 254 / best + 1;
+}
+
+// window sums for windows [win_lo, win_hi) -> host, internal packed xyzz images (XW words each)
+template <class Cv>
+static int32_t msm_windows(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
+                           u32 c, u32 nwin, u32 win_lo, u32 win_hi, u32* host_sums) {
+    const u32 W = win_hi - win_lo;
+    const u32 nb = 1u << (c - 1);
+    // segment length: keep >= ~256K lanes in flight, at most 128 additions per lane
+    u32 seg = 16;
+    while (seg < 128 && (double)n * W / seg > 262144.0) seg <<= 1;
+    const u32 nseg = (u32)((n + seg - 1) / seg);
+    const u32 L = 32;                                              // buckets per thread in the reduction
+    const u32 bpw = (nb + 256 * L - 1) / (256 * L);                // reduction blocks per window
+    const u32 heavy_cap = (u32)(((size_t)W * nseg) / (FIX_LIGHT - 1) + 1);
+    const bool on_dev = flags & DVN_MSM_SCALARS_ON_DEVICE;
+
+    CarverSize cs;
+    if (!on_dev) cs.take(n * 32);
+    cs.take((size_t)W * n * 4); cs.take((size_t)W * n * 4);          // digits, sorted
+    cs.take((size_t)W * nb * 4 * 3); cs.take((size_t)W * 4 + 4);      // counts, offsets, cursor; totals + heavy_count
+    cs.take((size_t)heavy_cap * 4);
+    cs.take((size_t)W * nb * Cv::XW * 4);                             // bucket sums
+    cs.take((size_t)W * nseg * Cv::XW * 4); cs.take((size_t)W * nseg * Cv::XW * 4);   // edges
+    cs.take((size_t)W * bpw * Cv::XW * 4); cs.take((size_t)W * Cv::XW * 4);
+    TRY(ensure_ws(ctx, cs.off + 4096));
+    Carver cv(ctx->ws);
+    const u32* d_scalars;
+    if (!on_dev) {
+        u32* tmp = cv.take<u32>(n * 8);
+        HIP_TRY(hipMemcpyAsync(tmp, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+        d_scalars = tmp;
+    } else d_scalars = (const u32*)scalars;
+    u32* digits = cv.take<u32>((size_t)W * n);
+    u32* sorted = cv.take<u32>((size_t)W * n);
+    u32* counts = cv.take<u32>((size_t)W * nb * 3);
+    u32* offsets = counts + (size_t)W * nb;
+    u32* cursor = offsets + (size_t)W * nb;
+    u32* totals = cv.take<u32>(W + 1);
+    u32* heavy_count = totals + W;
+    u32* heavy_list = cv.take<u32>(heavy_cap);
+    u32* buckets = cv.take<u32>((size_t)W * nb * Cv::XW);
+    u32* edge_first = cv.take<u32>((size_t)W * nseg * Cv::XW);
+    u32* edge_last = cv.take<u32>((size_t)W * nseg * Cv::XW);
+    u32* partials = cv.take<u32>((size_t)W * bpw * Cv::XW);
+    u32* wsums = cv.take<u32>((size_t)W * Cv::XW);
+
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipEventRecord(ctx->ev[0], st));
+    HIP_TRY(hipMemsetAsync(counts, 0, (size_t)W * nb * 4, st));
+    HIP_TRY(hipMemsetAsync(totals, 0, (size_t)(W + 1) * 4, st));
+    k_digits<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_scalars, n, c, nwin, win_lo, win_hi, digits, counts);
+    k_scan<<<W, 1024, 0, st>>>(counts, offsets, cursor, totals, nb);
+    k_scatter<<<(unsigned)(((size_t)W * n + 255) / 256), 256, 0, st>>>(digits, cursor, sorted, n, W, nb);
+    HIP_TRY(hipEventRecord(ctx->ev[2], st));
+    k_accumulate<Cv><<<(unsigned)(((size_t)W * nseg + 127) / 128), 128, 0, st>>>(pts->d, off, sorted, offsets, counts, totals, buckets,
+                                                                              edge_first, edge_last, n, nb, seg, nseg, W);
+    HIP_TRY(hipEventRecord(ctx->ev[3], st));
+    k_fix<Cv><<<(unsigned)(((size_t)W * nb + 127) / 128), 128, 0, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list,
+                                                                     heavy_count, W, nb, seg, nseg, heavy_cap);
+    const size_t sh_bytes = (size_t)256 * Cv::XW * 4;
+    k_fix_heavy<Cv><<<512, 256, sh_bytes, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list, heavy_count, nb, seg, nseg, heavy_cap);
+    k_bucket_reduce<Cv><<<W * bpw, 256, sh_bytes, st>>>(buckets, partials, nb, L, bpw);
+    k_window_finalize<Cv><<<(W + 63) / 64, 64, 0, st>>>(partials, wsums, W, bpw);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev[1], st));
+    HIP_TRY(hipMemcpyAsync(host_sums, wsums, (size_t)W * Cv::XW * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipEventElapsedTime(&ctx->last_ms[0], ctx->ev[0], ctx->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ctx->last_ms[1], ctx->ev[2], ctx->ev[3]));
+    return DVN_OK;
+}
+
+template <class Cv> static typename Cv::X horner(const u32* sums /* nwin * XW internal */, u32 nwin, u32 c) {
+    typename Cv::X acc = Cv::infinity();
+    for (int w = (int)nwin - 1; w >= 0; --w) {
+        for (u32 k = 0; k < c; ++k) acc = Cv::dbl(acc);
+        acc = Cv::add(acc, Cv::load_xyzz_internal(sums + (size_t)w * Cv::XW));
+    }
+    return acc;
+}
+// affine -> gnark Jacobian image (x, y, 1) / infinity (1, 1, 0)
+template <class Cv> static void write_jac(const typename Cv::X& p, uint64_t* out) {
+    typedef Ops<decltype(p.x)> O;
+    u32* w = (u32*)out;
+    const int FW = O::WORDS;
+    if (Cv::is_inf(p)) {
+        O::to_ext(O::one(), w); O::to_ext(O::one(), w + FW); O::to_ext(O::zero(), w + 2 * FW);
+        return;
+    }
+    typename Cv::A a = Cv::to_affine(p);
+    O::to_ext(a.x, w); O::to_ext(a.y, w + FW); O::to_ext(O::one(), w + 2 * FW);
+}
+
+template <class Cv>
+static int32_t msm_full(dvn_ctx* ctx, const dvn_points* pts, int curve, size_t off, size_t n, const uint64_t* scalars, uint32_t flags, uint64_t* out_jac) {
+    TRY(enter(ctx));
+    if (!pts || !out_jac || (!scalars && n)) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    if (pts->curve != curve) return fail(DVN_ERR_INVALID_ARG, "point set is G%d, call is G%d", pts->curve, curve);
+    if (off > pts->n || n > pts->n - off) return fail(DVN_ERR_INVALID_ARG, "len(points) != len(scalars): range [%zu, %zu) outside point set of %zu", off, off + n, pts->n);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (n == 0) { write_jac<Cv>(Cv::infinity(), out_jac); ctx->last_ms[0] = ctx->last_ms[1] = 0.f; return DVN_OK; }
+    u32 c, nwin; msm_plan(n, &c, &nwin);
+    std::vector<u32> sums((size_t)nwin * Cv::XW);
+    TRY(msm_windows<Cv>(ctx, pts, off, n, scalars, flags, c, nwin, 0, nwin, sums.data()));
+    write_jac<Cv>(horner<Cv>(sums.data(), nwin, c), out_jac);
+    return DVN_OK;
+}
+

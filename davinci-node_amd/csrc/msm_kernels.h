@@ -1,0 +1,326 @@
+// Pippenger MSM kernels for BN254 G1 / G2 on gfx950.
+//
+// Replaces gnark-crypto's G1Jac.MultiExp / G2Jac.MultiExp, which groth16.Prove calls
+// five times per proof (/root/reference/prover/prover_cpu.go:37 -> gnark backend/groth16/bn254/prove.go).
+//
+// Pipeline (DESIGN.md "MSM"):
+//   k_digits      scalar (Montgomery) -> canonical -> signed c-bit digits for every window; per-bucket histogram
+//   k_scan        exclusive scan of the histogram per window
+//   k_scatter     counting sort of (point index | sign) by bucket, per window
+//   k_accumulate  HOT KERNEL: one lane per fixed-size SEGMENT of the sorted list (not per bucket), so every
+//                 lane of a wave does exactly SEG mixed additions whatever the scalar distribution is; runs
+//                 that a segment shares with its neighbours are written as edge partials
+//   k_fix / k_fix_heavy   stitch the edge partials of buckets that span segments (heavy = block-cooperative)
+//   k_bucket_reduce + k_window_finalize   sum_b b * B_b per window: chunked running sums + small scalar mul +
+//                 LDS tree
+//   host          Horner combine of the <= 32 window sums (O(254) group operations)
+#pragma once
+#include "bn254_curve.h"
+
+namespace dvn {
+
+constexpr u32 SIGN_BIT = 0x80000000u;
+
+__device__ __forceinline__ void load_words16(const u32* __restrict__ p, u32* w, int nwords) {
+    // nwords is a multiple of 4 and p is 16-byte aligned
+    for (int i = 0; i < nwords; i += 4) {
+        uint4 v = *reinterpret_cast<const uint4*>(p + i);
+        w[i] = v.x; w[i + 1] = v.y; w[i + 2] = v.z; w[i + 3] = v.w;
+    }
+}
+__device__ __forceinline__ void store_words16(u32* __restrict__ p, const u32* w, int nwords) {
+    for (int i = 0; i < nwords; i += 4) *reinterpret_cast<uint4*>(p + i) = make_uint4(w[i], w[i + 1], w[i + 2], w[i + 3]);
+}
+
+template <class Cv> __device__ __forceinline__ typename Cv::A ld_affine(const u32* __restrict__ p) {
+    u32 w[Cv::AW];
+#pragma unroll
+    for (int i = 0; i < Cv::AW; i += 4) {
+        uint4 v = *reinterpret_cast<const uint4*>(p + i);
+        w[i] = v.x; w[i + 1] = v.y; w[i + 2] = v.z; w[i + 3] = v.w;
+    }
+    return Cv::load_affine_internal(w);
+}
+template <class Cv> __device__ __forceinline__ typename Cv::X ld_xyzz(const u32* __restrict__ p) {
+    u32 w[Cv::XW];
+#pragma unroll
+    for (int i = 0; i < Cv::XW; i += 4) {
+        uint4 v = *reinterpret_cast<const uint4*>(p + i);
+        w[i] = v.x; w[i + 1] = v.y; w[i + 2] = v.z; w[i + 3] = v.w;
+    }
+    return Cv::load_xyzz_internal(w);
+}
+template <class Cv> __device__ __forceinline__ void st_xyzz(const typename Cv::X& pt, u32* __restrict__ p) {
+    u32 w[Cv::XW];
+    Cv::store_xyzz_internal(pt, w);
+#pragma unroll
+    for (int i = 0; i < Cv::XW; i += 4) *reinterpret_cast<uint4*>(p + i) = make_uint4(w[i], w[i + 1], w[i + 2], w[i + 3]);
+}
+
+// ---- points: external gnark image -> internal image, in place ------------------------------------------
+template <class Cv> __global__ void k_points_to_internal(u32* __restrict__ pts, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 w[Cv::AW];
+    load_words16(pts + i * Cv::AW, w, Cv::AW);
+    typename Cv::A p = Cv::affine_from_ext(w);
+    Cv::store_affine_internal(p, w);
+    store_words16(pts + i * Cv::AW, w, Cv::AW);
+}
+template <class Cv> __global__ void k_points_to_external(const u32* __restrict__ pts, u32* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    typename Cv::A p = ld_affine<Cv>(pts + i * Cv::AW);
+    u32 w[Cv::AW];
+    Cv::affine_to_ext(p, w);
+    store_words16(out + i * Cv::AW, w, Cv::AW);
+}
+// P_i = base + i*step, written in internal affine form; base/step are internal affine images
+template <class Cv> __global__ void k_points_progression(u32* __restrict__ pts, size_t n, const u32* __restrict__ base_step, u32 chunk) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t lo = t * chunk;
+    if (lo >= n) return;
+    size_t hi = lo + chunk < n ? lo + chunk : n;
+    typename Cv::A base = ld_affine<Cv>(base_step), step = ld_affine<Cv>(base_step + Cv::AW);
+    typename Cv::X cur = Cv::add_mixed(Cv::mul_small(Cv::from_affine(step), (u32)lo), base);
+    for (size_t i = lo; i < hi; ++i) {
+        typename Cv::A a = Cv::to_affine(cur);
+        u32 w[Cv::AW];
+        Cv::store_affine_internal(a, w);
+        store_words16(pts + i * Cv::AW, w, Cv::AW);
+        cur = Cv::add_mixed(cur, step);
+    }
+}
+
+// ---- digits + histogram ----------------------------------------------------------------------------------
+// digits[(w - win_lo) * n + i] = magnitude | sign<<31 (0 = skip).  counts[(w - win_lo) * nb + magnitude-1]++
+static __global__ void k_digits(const u32* __restrict__ scalars, size_t n, u32 c, u32 nwin, u32 win_lo, u32 win_hi,
+                         u32* __restrict__ digits, u32* __restrict__ counts) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 w[8];
+    load_words16(scalars + i * 8, w, 8);
+    Fr k = fe_ext_mont_to_canonical<FrCfg>(w);
+    u32 kw[9];
+    {
+        u32 t[8]; fe_pack<FrCfg>(k, t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kw[j] = t[j];
+        kw[8] = 0;
+    }
+    const u32 nb = 1u << (c - 1), mask = (1u << c) - 1;
+    u32 carry = 0;
+    for (u32 win = 0; win < win_hi; ++win) {
+        const u32 bit = win * c;
+        u32 d = carry;
+        if (bit < 256) {
+            const u32 wi = bit >> 5, sh = bit & 31;
+            u64 two = (u64)kw[wi] | ((u64)kw[wi + 1] << 32);
+            d += (u32)(two >> sh) & mask;
+        }
+        carry = 0;
+        u32 enc = 0;
+        if (d > nb) { d = (1u << c) - d; carry = 1; enc = d ? (d | SIGN_BIT) : 0; }
+        else enc = d;
+        if (win >= win_lo) {
+            digits[(size_t)(win - win_lo) * n + i] = enc;
+            if (enc) atomicAdd(&counts[(size_t)(win - win_lo) * nb + (enc & ~SIGN_BIT) - 1], 1u);
+        }
+    }
+    (void)nwin;
+}
+
+// one block per window: offsets = exclusive scan of counts; totals[w] = number of entries
+static __global__ void k_scan(const u32* __restrict__ counts, u32* __restrict__ offsets, u32* __restrict__ cursor,
+                       u32* __restrict__ totals, u32 nb) {
+    __shared__ u32 part[1024];
+    const u32 w = blockIdx.x, t = threadIdx.x, T = blockDim.x;
+    const u32 per = (nb + T - 1) / T;
+    const u32 lo = t * per, hi = min(lo + per, nb);
+    const u32* cw = counts + (size_t)w * nb;
+    u32 s = 0;
+    for (u32 b = lo; b < hi; ++b) s += cw[b];
+    part[t] = s;
+    __syncthreads();
+    for (u32 d = 1; d < T; d <<= 1) {
+        u32 v = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    u32 run = part[t] - s;
+    for (u32 b = lo; b < hi; ++b) {
+        offsets[(size_t)w * nb + b] = run;
+        cursor[(size_t)w * nb + b] = run;
+        run += cw[b];
+    }
+    if (t == T - 1) totals[w] = part[t];
+}
+
+static __global__ void k_scatter(const u32* __restrict__ digits, u32* __restrict__ cursor, u32* __restrict__ sorted,
+                          size_t n, u32 nwin_local, u32 nb) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n * nwin_local) return;
+    const u32 w = (u32)(g / n);
+    const u32 i = (u32)(g - (size_t)w * n);
+    const u32 enc = digits[g];
+    if (!enc) return;
+    const u32 b = (enc & ~SIGN_BIT) - 1;
+    const u32 pos = atomicAdd(&cursor[(size_t)w * nb + b], 1u);
+    sorted[(size_t)w * n + pos] = i | (enc & SIGN_BIT);
+}
+
+// ---- HOT KERNEL: segment accumulation -------------------------------------------------------------------
+// lane = (window w, segment k): entries [k*seg, min((k+1)*seg, totals[w])) of window w's sorted list.
+template <class Cv>
+__global__ __launch_bounds__(128) void k_accumulate(const u32* __restrict__ points, size_t pts_off,
+                                                    const u32* __restrict__ sorted, const u32* __restrict__ offsets,
+                                                    const u32* __restrict__ counts, const u32* __restrict__ totals,
+                                                    u32* __restrict__ bucket_sums, u32* __restrict__ edge_first,
+                                                    u32* __restrict__ edge_last, size_t n, u32 nb, u32 seg, u32 nseg,
+                                                    u32 nwin_local) {
+    typedef typename Cv::X X;
+    typedef typename Cv::A A;
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 w = (u32)(g / nseg);
+    if (w >= nwin_local) return;
+    const u32 k = (u32)(g - (size_t)w * nseg);
+    const u32 total = totals[w];
+    const u32 pos0 = k * seg;
+    if (pos0 >= total) return;
+    const u32 pos1 = min(pos0 + seg, total);
+    const u32* off = offsets + (size_t)w * nb;
+    const u32* cnt = counts + (size_t)w * nb;
+    const u32* src = sorted + (size_t)w * n;
+    // bucket containing pos0: largest b with off[b] <= pos0 (the last of equal offsets is the non-empty one)
+    u32 lo = 0, hi = nb;
+    while (hi - lo > 1) { u32 mid = (lo + hi) >> 1; if (off[mid] <= pos0) lo = mid; else hi = mid; }
+    u32 b = lo;
+    u32 b_start = off[b], b_end = b_start + cnt[b];
+    X acc = Cv::infinity();
+    u32 x = pos0;
+    while (x < pos1) {
+        const u32 run_end = min(b_end, pos1);
+        for (; x < run_end; ++x) {
+            const u32 e = src[x];
+            A p = ld_affine<Cv>(points + (pts_off + (size_t)(e & ~SIGN_BIT)) * Cv::AW);
+            if (e & SIGN_BIT) p = Cv::neg(p);
+            acc = Cv::add_mixed(acc, p);
+        }
+        // flush the run [max(pos0,b_start), run_end) of bucket b
+        u32* dst;
+        if (b_start >= pos0 && b_end <= pos1) dst = bucket_sums + ((size_t)w * nb + b) * Cv::XW;
+        else if (max(pos0, b_start) == pos0) dst = edge_first + ((size_t)w * nseg + k) * Cv::XW;
+        else dst = edge_last + ((size_t)w * nseg + k) * Cv::XW;
+        st_xyzz<Cv>(acc, dst);
+        acc = Cv::infinity();
+        if (x < pos1) {   // advance to the next non-empty bucket (it starts at x)
+            do { ++b; } while (cnt[b] == 0);
+            b_start = off[b]; b_end = b_start + cnt[b];
+        }
+    }
+}
+
+// lane per bucket: empty -> infinity; spanning <= FIX_LIGHT segments -> stitch serially; more -> heavy list
+constexpr u32 FIX_LIGHT = 24;
+template <class Cv>
+__global__ __launch_bounds__(128) void k_fix(const u32* __restrict__ offsets, const u32* __restrict__ counts,
+                                             u32* __restrict__ bucket_sums, const u32* __restrict__ edge_first,
+                                             const u32* __restrict__ edge_last, u32* __restrict__ heavy_list,
+                                             u32* __restrict__ heavy_count, u32 nwin_local, u32 nb, u32 seg, u32 nseg,
+                                             u32 heavy_cap) {
+    typedef typename Cv::X X;
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (size_t)nwin_local * nb) return;
+    const u32 w = (u32)(g / nb);
+    const u32 c = counts[g];
+    u32* dst = bucket_sums + g * Cv::XW;
+    if (c == 0) { st_xyzz<Cv>(Cv::infinity(), dst); return; }
+    const u32 o = offsets[g], e = o + c;
+    const u32 ks = o / seg, ke = (e - 1) / seg;
+    if (ks == ke) return;                       // complete inside one segment: written by k_accumulate
+    if (ke - ks + 1 > FIX_LIGHT) {
+        const u32 slot = atomicAdd(heavy_count, 1u);
+        if (slot < heavy_cap) heavy_list[slot] = (u32)g;
+        return;
+    }
+    const u32* first = edge_first + (size_t)w * nseg * Cv::XW;
+    const u32* last = edge_last + (size_t)w * nseg * Cv::XW;
+    X acc = ld_xyzz<Cv>(((o % seg) == 0 ? first : last) + (size_t)ks * Cv::XW);
+    for (u32 k = ks + 1; k <= ke; ++k) acc = Cv::add(acc, ld_xyzz<Cv>(first + (size_t)k * Cv::XW));
+    st_xyzz<Cv>(acc, dst);
+}
+
+// block-cooperative sum of points in shared memory (blockDim.x power of two <= 256); result in lane 0
+template <class Cv> __device__ typename Cv::X block_sum(typename Cv::X v, u32* sh /* blockDim.x * XW words */) {
+    const u32 t = threadIdx.x;
+    for (u32 stride = blockDim.x >> 1; stride >= 1; stride >>= 1) {
+        if (t >= stride && t < 2 * stride) Cv::store_xyzz_internal(v, sh + (size_t)(t - stride) * Cv::XW);
+        __syncthreads();
+        if (t < stride) v = Cv::add(v, Cv::load_xyzz_internal(sh + (size_t)t * Cv::XW));
+        __syncthreads();
+    }
+    return v;
+}
+
+template <class Cv>
+__global__ __launch_bounds__(256) void k_fix_heavy(const u32* __restrict__ offsets, const u32* __restrict__ counts,
+                                                   u32* __restrict__ bucket_sums, const u32* __restrict__ edge_first,
+                                                   const u32* __restrict__ edge_last, const u32* __restrict__ heavy_list,
+                                                   const u32* __restrict__ heavy_count, u32 nb, u32 seg, u32 nseg, u32 heavy_cap) {
+    typedef typename Cv::X X;
+    extern __shared__ __align__(16) u32 sh[];
+    const u32 nheavy = min(*heavy_count, heavy_cap);
+    for (u32 h = blockIdx.x; h < nheavy; h += gridDim.x) {
+        const u32 g = heavy_list[h];
+        const u32 w = g / nb;
+        const u32 o = offsets[g], e = o + counts[g];
+        const u32 ks = o / seg, ke = (e - 1) / seg;
+        const u32* first = edge_first + (size_t)w * nseg * Cv::XW;
+        const u32* last = edge_last + (size_t)w * nseg * Cv::XW;
+        X acc = Cv::infinity();
+        for (u32 k = ks + threadIdx.x; k <= ke; k += blockDim.x) {
+            const u32* src = (k == ks && (o % seg) != 0) ? last : first;
+            acc = Cv::add(acc, ld_xyzz<Cv>(src + (size_t)k * Cv::XW));
+        }
+        acc = block_sum<Cv>(acc, sh);
+        if (threadIdx.x == 0) st_xyzz<Cv>(acc, bucket_sums + (size_t)g * Cv::XW);
+        __syncthreads();
+    }
+}
+
+// ---- bucket reduction: window sum = sum_{b=1..nb} b * B_b -------------------------------------------------
+// block handles blockDim.x * L consecutive buckets of one window; thread handles L of them.
+template <class Cv>
+__global__ __launch_bounds__(256) void k_bucket_reduce(const u32* __restrict__ bucket_sums, u32* __restrict__ partials,
+                                                       u32 nb, u32 L, u32 blocks_per_window) {
+    typedef typename Cv::X X;
+    extern __shared__ __align__(16) u32 sh[];
+    const u32 w = blockIdx.x / blocks_per_window, blk = blockIdx.x % blocks_per_window;
+    const u32 first = (blk * blockDim.x + threadIdx.x) * L;     // 0-based index of this thread's first bucket
+    X run = Cv::infinity(), tot = Cv::infinity();
+    if (first < nb) {
+        const u32 last = min(first + L, nb);
+        const u32* base = bucket_sums + (size_t)w * nb * Cv::XW;
+        for (u32 b = last; b-- > first;) {
+            run = Cv::add(run, ld_xyzz<Cv>(base + (size_t)b * Cv::XW));
+            tot = Cv::add(tot, run);
+        }
+        // tot = sum_j (j - first + 1) * B_j ; bucket j (0-based) has weight j + 1 = (j - first + 1) + first
+        if (first) tot = Cv::add(tot, Cv::mul_small(run, first));
+    }
+    tot = block_sum<Cv>(tot, sh);
+    if (threadIdx.x == 0) st_xyzz<Cv>(tot, partials + (size_t)blockIdx.x * Cv::XW);
+}
+template <class Cv>
+__global__ void k_window_finalize(const u32* __restrict__ partials, u32* __restrict__ window_sums, u32 nwin_local,
+                                  u32 blocks_per_window) {
+    typedef typename Cv::X X;
+    const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwin_local) return;
+    X acc = Cv::infinity();
+    for (u32 i = 0; i < blocks_per_window; ++i) acc = Cv::add(acc, ld_xyzz<Cv>(partials + ((size_t)w * blocks_per_window + i) * Cv::XW));
+    st_xyzz<Cv>(acc, window_sums + (size_t)w * Cv::XW);
+}
+
+}  // namespace dvn

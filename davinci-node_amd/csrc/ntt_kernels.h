@@ -1,0 +1,135 @@
+// Radix-2 NTT over BN254 Fr on gfx950 with gnark-crypto's fft.Domain semantics:
+//   DIF: natural in -> bit-reversed out, butterfly (a, b) -> (a + b, (a - b) * w)
+//   DIT: bit-reversed in -> natural out, butterfly (a, b) -> (a + b * w, a - b * w)
+//   FFT(OnCoset) pre-scales by g^i (bit-reversed index when DIT); FFTInverse post-scales by 1/n (and g^-i,
+//   bit-reversed index when DIF).  No implicit bit reversal anywhere.
+// Used by groth16 computeH (7 transforms per proof; /root/reference/prover/prover_cpu.go:37 -> gnark prove.go).
+//
+// One launch = one PASS of up to 8 consecutive radix-2 stages on LDS-resident tiles: a tile is I (<= 8)
+// neighbouring sub-problems of 2^K elements, so every global access is a run of I * 32 B = 256 B and the
+// 2^K * I * 32 B tile (<= 64 KiB) sees K stages for one HBM read + one HBM write.  Twiddles come from
+// per-stage tables table_s[k] = w^(k * 2^s) in HBM (contiguous in k, i.e. coalesced across a tile row); the
+// late, small tables stay in L2 / Infinity Cache.
+//
+// Data words are gnark Montgomery words (x * 2^256), read as the internal form of x * 2^-5; the transform is
+// linear so no conversion pass is needed (bn254_field.h header).  Twiddles / scale factors are true internal
+// forms.
+#pragma once
+#include "bn254_field.h"
+
+namespace dvn {
+
+__device__ __forceinline__ Fr ld_fr(const u32* __restrict__ p) {
+    uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 4);
+    u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    return fe_unpack<FrCfg>(w);
+}
+// weak form -> canonical -> 8 words
+__device__ __forceinline__ void st_fr(const Fr& v, u32* __restrict__ p) {
+    u32 w[8];
+    fe_pack<FrCfg>(fe_canonical<FrCfg>(v), w);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    *reinterpret_cast<uint4*>(p + 4) = make_uint4(w[4], w[5], w[6], w[7]);
+}
+// LDS staging keeps weak form (no canonicalisation between stages)
+__device__ __forceinline__ void st_fr_weak(const Fr& v, u32* p) {
+    u32 w[8];
+    fe_pack<FrCfg>(v, w);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    *reinterpret_cast<uint4*>(p + 4) = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+// out[k] = base^(k) * first, k < count; thread handles `chunk` consecutive entries.  base/first internal form.
+__global__ void k_powers(u32* __restrict__ out, const u32* __restrict__ base_first, size_t count, u32 chunk) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t lo = t * chunk;
+    if (lo >= count) return;
+    size_t hi = lo + chunk < count ? lo + chunk : count;
+    Fr base = ld_fr(base_first), cur = fe_mul<FrCfg>(fe_pow_u64<FrCfg>(base, (u64)lo), ld_fr(base_first + 8));
+    for (size_t k = lo; k < hi; ++k) { st_fr(cur, out + k * 8); cur = fe_mul<FrCfg>(cur, base); }
+}
+
+struct NttScale {
+    const u32* lo;     // lo[j]  = f^j * c,            j < 2^lo_bits   (mode 2); lo[0] = constant (mode 1)
+    const u32* hi;     // hi[j]  = f^(j << lo_bits),   j < n >> lo_bits
+    u32 lo_bits;
+    int mode;          // 0 none, 1 constant, 2 power table
+    int bitrev;        // exponent = bitrev(i) instead of i
+    int when;          // 1 = at load (pre-scale), 2 = at store (post-scale)
+};
+
+__device__ __forceinline__ Fr ntt_scale_factor(const NttScale& sc, u32 i, u32 log_n) {
+    if (sc.mode == 1) return ld_fr(sc.lo);
+    const u32 e = sc.bitrev ? (__brev(i) >> (32 - log_n)) : i;
+    Fr f = ld_fr(sc.lo + (size_t)(e & ((1u << sc.lo_bits) - 1)) * 8);
+    if (log_n > sc.lo_bits) f = fe_mul<FrCfg>(f, ld_fr(sc.hi + (size_t)(e >> sc.lo_bits) * 8));
+    return f;
+}
+
+// stages [sa, sb) of a 2^log_n transform; dit = 0: ascending s (DIF), dit = 1: descending s (DIT)
+__global__ __launch_bounds__(512) void k_ntt_pass(u32* __restrict__ data, const u32* __restrict__ tw, u32 log_n,
+                                                  u32 sa, u32 sb, int dit, u32 log_i, NttScale sc) {
+    extern __shared__ __align__(16) u32 lds[];
+    const u32 K = sb - sa, Lb = log_n - sb, I = 1u << log_i;
+    const u32 E = I << K;
+    const u32 n = 1u << log_n;
+    const u32 sp0 = blockIdx.x << log_i;                 // first sub-problem of this tile
+    const u32 inner_mask = (1u << Lb) - 1;
+    // ---- load
+    for (u32 le = threadIdx.x; le < E; le += blockDim.x) {
+        const u32 q = le & (I - 1), D = le >> log_i, sp = sp0 + q;
+        const u32 gi = ((sp >> Lb) << (Lb + K)) | (D << Lb) | (sp & inner_mask);
+        Fr v = ld_fr(data + (size_t)gi * 8);
+        if (sc.mode && sc.when == 1) v = fe_mul<FrCfg>(v, ntt_scale_factor(sc, gi, log_n));
+        st_fr_weak(v, lds + (size_t)le * 8);
+    }
+    __syncthreads();
+    // ---- butterflies
+    for (u32 t = 0; t < K; ++t) {
+        const u32 s = dit ? (sb - 1 - t) : (sa + t);
+        const u32 tl = s - sa;
+        const u32 dshift = K - 1 - tl, dist = 1u << dshift;
+        const u32* table = tw + ((size_t)n - (n >> s)) * 8;
+        for (u32 u = threadIdx.x; u < (E >> 1); u += blockDim.x) {
+            const u32 q = u & (I - 1), dp = u >> log_i;
+            const u32 low = dp & (dist - 1);
+            const u32 D0 = ((dp >> dshift) << (dshift + 1)) | low, D1 = D0 | dist;
+            const u32 j = (low << Lb) | ((sp0 + q) & inner_mask);
+            const Fr w = ld_fr(table + (size_t)j * 8);
+            u32* pa = lds + (size_t)((D0 << log_i) | q) * 8;
+            u32* pb = lds + (size_t)((D1 << log_i) | q) * 8;
+            const Fr a = ld_fr(pa), b = ld_fr(pb);
+            if (!dit) {
+                st_fr_weak(fe_add<FrCfg>(a, b), pa);
+                st_fr_weak(fe_mul<FrCfg>(fe_sub<FrCfg>(a, b), w), pb);
+            } else {
+                const Fr bt = fe_mul<FrCfg>(b, w);
+                st_fr_weak(fe_add<FrCfg>(a, bt), pa);
+                st_fr_weak(fe_sub<FrCfg>(a, bt), pb);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- store
+    for (u32 le = threadIdx.x; le < E; le += blockDim.x) {
+        const u32 q = le & (I - 1), D = le >> log_i, sp = sp0 + q;
+        const u32 gi = ((sp >> Lb) << (Lb + K)) | (D << Lb) | (sp & inner_mask);
+        Fr v = ld_fr(lds + (size_t)le * 8);
+        if (sc.mode && sc.when == 2) v = fe_mul<FrCfg>(v, ntt_scale_factor(sc, gi, log_n));
+        st_fr(v, data + (size_t)gi * 8);
+    }
+}
+
+// computeH pointwise step: a[i] = (a[i] * b[i] - c[i]) * den   (all words external Montgomery)
+// k1 = internal form of den * 2^5, k2 = internal form of den (see bn254_field.h on the 2^-5 reading)
+__global__ void k_h_pointwise(u32* __restrict__ a, const u32* __restrict__ b, const u32* __restrict__ c,
+                              const u32* __restrict__ k1k2, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fr k1 = ld_fr(k1k2), k2 = ld_fr(k1k2 + 8);
+    Fr ab = fe_mul<FrCfg>(fe_mul<FrCfg>(ld_fr(a + i * 8), ld_fr(b + i * 8)), k1);
+    Fr cd = fe_mul<FrCfg>(ld_fr(c + i * 8), k2);
+    st_fr(fe_sub<FrCfg>(ab, cd), a + i * 8);
+}
+
+}  // namespace dvn

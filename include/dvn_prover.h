@@ -1,0 +1,116 @@
+/* dvn_prover.h -- C-ABI of the MI355X-native prover backend (libdvn_prover.so).
+ *
+ * This is the drop-in boundary of SURVEY.md §8(b): the entry points a build-tagged Go file next to
+ * /root/reference/prover/prover_gpu.go would bind through cgo in place of the ICICLE
+ * calls behind gpugroth16.Prove (prover/prover_gpu.go:33).  Every function is thread-safe, calls
+ * hipSetDevice on entry (cgo calls arrive on arbitrary OS threads), never throws or aborts, and never keeps
+ * a caller pointer after it returns (cgo pointer rule): host inputs are copied to the device before return
+ * and outputs are written into caller buffers.
+ *
+ * Data formats are gnark-crypto's in-memory images, zero-copy from Go slices:
+ *   fr.Element / fp.Element   4 x uint64 little-endian limbs, Montgomery form, R = 2^256
+ *   G1Affine {X, Y}           8 x uint64, infinity = (0, 0)
+ *   G2Affine {X.A0, X.A1, Y.A0, Y.A1}   16 x uint64
+ *   G1Jac {X, Y, Z}           12 x uint64;  G2Jac 24 x uint64
+ *
+ * Return value: 0 = DVN_OK, negative = error; dvn_last_error(ctx) gives the message of the calling thread's
+ * last failure.
+ */
+#ifndef DVN_PROVER_H
+#define DVN_PROVER_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVN_OK 0
+#define DVN_ERR_INVALID_ARG (-1)   /* NULL pointer, bad range, len(points) != len(scalars) (MultiExp's error) */
+#define DVN_ERR_DEVICE (-2)        /* a HIP call failed; message carries hipGetErrorString */
+#define DVN_ERR_NO_DEVICE (-3)     /* no usable gfx950 device / requested ordinal missing */
+#define DVN_ERR_OOM (-4)
+#define DVN_ERR_UNSUPPORTED (-5)   /* e.g. curve other than BN254 (mirrors prover/prover_gpu.go:58-60) */
+#define DVN_ERR_INJECTED (-6)      /* DVN_FORCE_FAIL=1 test hook: exercises the caller's GPU->CPU fallback */
+
+typedef struct dvn_ctx dvn_ctx;
+typedef struct dvn_points dvn_points;   /* device-resident affine point set (one proving-key array) */
+typedef struct dvn_domain dvn_domain;   /* fft.Domain: twiddle tables for one size, device-resident */
+
+/* ---- lifetime ---------------------------------------------------------------------------------------- */
+/* Replaces icicle's device/runtime bring-up behind gpugroth16 (prover/prover_gpu.go:10-15).
+ * devs/ndev: HIP device ordinals this context may use (NULL/0 = device 0).  One context per process-GPU. */
+int32_t dvn_init(const int* devs, int ndev, dvn_ctx** out);
+void dvn_shutdown(dvn_ctx* ctx);
+const char* dvn_last_error(const dvn_ctx* ctx);
+const char* dvn_version(void);
+
+/* ---- device memory helpers (bench/test harness; also used by the host orchestration) ------------------ */
+int32_t dvn_malloc(dvn_ctx* ctx, size_t bytes, void** dptr);
+int32_t dvn_free(dvn_ctx* ctx, void* dptr);
+int32_t dvn_memcpy_h2d(dvn_ctx* ctx, void* dst, const void* src, size_t bytes);
+int32_t dvn_memcpy_d2h(dvn_ctx* ctx, void* dst, const void* src, size_t bytes);
+int32_t dvn_synchronize(dvn_ctx* ctx);
+
+/* ---- proving-key point arrays ------------------------------------------------------------------------ */
+/* Upload once per proving key (what icicle_bn254.ProvingKey's lazily uploaded device pointers hold,
+ * SURVEY.md row a16; constructed at /root/reference/circuits/artifacts.go:634-637).
+ * xy_mont: N x 8 (G1) or N x 16 (G2) uint64. */
+int32_t dvn_points_upload_g1(dvn_ctx* ctx, const uint64_t* xy_mont, size_t n, dvn_points** out);
+int32_t dvn_points_upload_g2(dvn_ctx* ctx, const uint64_t* xy_mont, size_t n, dvn_points** out);
+/* Synthetic SRS generated on the device: P_i = [s0]G + i*[s1]G with (s0, s1) the first two Fr of the
+ * SplitMix64 stream `seed`.  Bench/test input generator. */
+int32_t dvn_points_synthetic_g1(dvn_ctx* ctx, uint64_t seed, size_t n, dvn_points** out);
+int32_t dvn_points_synthetic_g2(dvn_ctx* ctx, uint64_t seed, size_t n, dvn_points** out);
+/* Copy points [off, off+n) back to the host in gnark's affine Montgomery image. */
+int32_t dvn_points_download(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, uint64_t* xy_mont);
+size_t dvn_points_len(const dvn_points* pts);
+int32_t dvn_points_free(dvn_ctx* ctx, dvn_points* pts);
+
+/* ---- MultiExp (replaces gnark-crypto G1Jac.MultiExp / G2Jac.MultiExp) -------------- */
+/* result = sum_{i<n} scalars[i] * points[off+i].  scalars_mont: n x 4 uint64 on the HOST.
+ * out_jac: a valid Jacobian representative (this library returns the affine normal form with Z = 1, or
+ * (1,1,0) for infinity); parity with gnark is defined after affine normalisation.
+ * flags: DVN_MSM_* bits. */
+#define DVN_MSM_DEFAULT 0u
+#define DVN_MSM_SCALARS_ON_DEVICE 1u   /* scalars_mont is a device pointer (HBM-resident witness) */
+int32_t dvn_msm_g1(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars_mont,
+                   uint32_t flags, uint64_t out_jac[12]);
+int32_t dvn_msm_g2(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars_mont,
+                   uint32_t flags, uint64_t out_jac[24]);
+/* Window-sharded variant for multi-GPU: this rank accumulates windows
+ * [win_lo, win_hi) of the `nwin` windows dvn_msm_plan reports and returns one extended-Jacobian point
+ * (X, Y, ZZ, ZZZ; 16 x uint64 for G1) per window in window_sums; ranks exchange them (RCCL all-gather) and any rank
+ * finishes with dvn_msm_combine_g1. */
+int32_t dvn_msm_plan(size_t n, uint32_t* window_bits, uint32_t* nwin);
+int32_t dvn_msm_g1_windows(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars_mont,
+                           uint32_t flags, uint32_t win_lo, uint32_t win_hi, uint64_t* window_sums /* (win_hi-win_lo) x 16 */);
+int32_t dvn_msm_combine_g1(dvn_ctx* ctx, const uint64_t* window_sums /* nwin x 16 */, uint32_t nwin, uint32_t window_bits,
+                           uint64_t out_jac[12]);
+
+/* ---- fr/fft (replaces gnark-crypto fft.Domain) ------------------------------------- */
+#define DVN_DIF 0
+#define DVN_DIT 1
+int32_t dvn_ntt_domain(dvn_ctx* ctx, uint32_t log_n, dvn_domain** out);      /* fft.NewDomain(1 << log_n) */
+int32_t dvn_ntt_domain_free(dvn_ctx* ctx, dvn_domain* dom);
+/* Domain.FFT (inverse = 0) / Domain.FFTInverse (inverse = 1), in place on n = 2^log_n elements.
+ * data on the host (copied in and out) or, with DVN_NTT_DATA_ON_DEVICE, a device pointer. */
+#define DVN_NTT_DATA_ON_DEVICE 1u
+int32_t dvn_ntt(dvn_ctx* ctx, const dvn_domain* dom, uint64_t* data, int inverse, int decimation, int on_coset,
+                uint32_t flags);
+
+/* ---- groth16 computeH -------------------------------------------------------------- */
+/* a, b, c: len <= n elements each (host, or device with DVN_NTT_DATA_ON_DEVICE); h_out: n elements, the
+ * coefficients of h in bit-reversed order exactly as gnark's computeH leaves them. */
+int32_t dvn_groth16_compute_h(dvn_ctx* ctx, const dvn_domain* dom, const uint64_t* a, const uint64_t* b,
+                              const uint64_t* c, size_t len, uint64_t* h_out, uint32_t flags);
+
+/* ---- timing of the last call's kernels, measured with HIP events on the library's own stream ---------- */
+/* which: 0 = whole device section of the last MSM/NTT call, 1 = its dominant kernel (MSM: bucket
+ * accumulation; NTT: sum of butterfly passes). */
+int32_t dvn_last_kernel_ms(dvn_ctx* ctx, int which, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
