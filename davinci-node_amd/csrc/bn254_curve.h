@@ -33,7 +33,7 @@ template <class F> struct Curve {
         return X{X3, Y3, V, W};
     }
     // 2*p (dbl-2008-s-1)
-    static DVN_HD X dbl(const X& p) {
+    static DVN_HD X dbl_impl(const X& p) {
         if (is_inf(p)) return p;
         F U = O::dbl(p.y), V = O::sqr(U), W = O::mul(U, V), S = O::mul(p.x, V);
         F xx = O::sqr(p.x), M = O::add(O::dbl(xx), xx);
@@ -42,7 +42,7 @@ template <class F> struct Curve {
         return X{X3, Y3, O::mul(V, p.zz), O::mul(W, p.zzz)};
     }
     // p + q, q affine (madd-2008-s); q may be infinity
-    static DVN_HD X add_mixed(const X& p, const A& q) {
+    static DVN_HD X add_mixed_impl(const X& p, const A& q) {
         if (is_inf(q)) return p;
         if (is_inf(p)) return X{q.x, q.y, O::one(), O::one()};
         F U2 = O::mul(q.x, p.zz), S2 = O::mul(q.y, p.zzz);
@@ -57,14 +57,14 @@ template <class F> struct Curve {
         return X{X3, Y3, O::mul(p.zz, PP), O::mul(p.zzz, PPP)};
     }
     // p + q (add-2008-s)
-    static DVN_HD X add(const X& p, const X& q) {
+    static DVN_HD X add_impl(const X& p, const X& q) {
         if (is_inf(q)) return p;
         if (is_inf(p)) return q;
         F U1 = O::mul(p.x, q.zz), U2 = O::mul(q.x, p.zz);
         F S1 = O::mul(p.y, q.zzz), S2 = O::mul(q.y, p.zzz);
         F P = O::sub(U2, U1), R = O::sub(S2, S1);
         if (O::is_zero(P)) {
-            if (O::is_zero(R)) return dbl(p);
+            if (O::is_zero(R)) return dbl_impl(p);
             return infinity();
         }
         F PP = O::sqr(P), PPP = O::mul(P, PP), Q = O::mul(U1, PP);
@@ -72,6 +72,14 @@ template <class F> struct Curve {
         F Y3 = O::sub(O::mul(R, O::sub(Q, X3)), O::mul(S1, PPP));
         return X{X3, Y3, O::mul(O::mul(p.zz, q.zz), PP), O::mul(O::mul(p.zzz, q.zzz), PPP)};
     }
+    // Group operations.  For G2 (Fp2: ~3x the code of G1 per operation) they are real calls: fully inlined,
+    // the G2 kernels exceed 10^5 instructions and need long-branch relaxation; outlined they stay small.
+    static DVN_NOINLINE X dbl_out(const X& p) { return dbl_impl(p); }
+    static DVN_NOINLINE X add_out(const X& p, const X& q) { return add_impl(p, q); }
+    static DVN_NOINLINE X add_mixed_out(const X& p, const A& q) { return add_mixed_impl(p, q); }
+    static DVN_HD X dbl(const X& p) { if constexpr (O::OUTLINE) return dbl_out(p); else return dbl_impl(p); }
+    static DVN_HD X add(const X& p, const X& q) { if constexpr (O::OUTLINE) return add_out(p, q); else return add_impl(p, q); }
+    static DVN_HD X add_mixed(const X& p, const A& q) { if constexpr (O::OUTLINE) return add_mixed_out(p, q); else return add_mixed_impl(p, q); }
     // [k]p for a small non-negative integer k (MSB-first double-and-add)
     static DVN_HD X mul_small(const X& p, u32 k) {
         X acc = infinity();

@@ -22,8 +22,10 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define DVN_HD __host__ __device__ __forceinline__
+#define DVN_NOINLINE __host__ __device__ __attribute__((noinline))
 #else
 #define DVN_HD inline
+#define DVN_NOINLINE __attribute__((noinline))
 #endif
 
 namespace dvn {
@@ -285,6 +287,7 @@ template <> struct Ops<Fp> {
         for (int i = 0; i < NL; ++i) z |= a.v[i];
         return z == 0; }
     static constexpr int WORDS = 8;   // external u32 words per element
+    static constexpr bool OUTLINE = false;
     static DVN_HD Fp load_internal(const u32* w) { u32 t[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) t[i] = w[i];
@@ -324,6 +327,7 @@ template <> struct Ops<Fp2> {
     static DVN_HD bool is_zero(const Fp2& a) { return B::is_zero(a.a0) && B::is_zero(a.a1); }
     static DVN_HD bool is_literal_zero(const Fp2& a) { return B::is_literal_zero(a.a0) && B::is_literal_zero(a.a1); }
     static constexpr int WORDS = 16;
+    static constexpr bool OUTLINE = true;
     static DVN_HD Fp2 load_internal(const u32* w) { return Fp2{B::load_internal(w), B::load_internal(w + 8)}; }
     static DVN_HD void store_internal(const Fp2& a, u32* w) { B::store_internal(a.a0, w); B::store_internal(a.a1, w + 8); }
     static DVN_HD Fp2 from_ext(const u32* w) { return Fp2{B::from_ext(w), B::from_ext(w + 8)}; }

@@ -132,22 +132,33 @@ static int32_t msm_windows(dvn_ctx* ctx, const dvn_points* pts, size_t off, size
     u32* wsums = cv.take<u32>((size_t)W * Cv::XW);
 
     hipStream_t st = ctx->stream;
+    static const bool dbg = getenv("DVN_DEBUG_SYNC") != nullptr;
+#define DBG_SYNC(name) do { if (dbg) { hipError_t _e = hipStreamSynchronize(st); fprintf(stderr, "[dvn] %s: %s\n", name, hipGetErrorString(_e)); fflush(stderr); if (_e != hipSuccess) return fail(DVN_ERR_DEVICE, "%s: %s", name, hipGetErrorString(_e)); } } while (0)
+    if (dbg) { fprintf(stderr, "[dvn] msm n=%zu c=%u W=%u nb=%u seg=%u nseg=%u bpw=%u heavy_cap=%u ws=%zu\n", n, c, W, nb, seg, nseg, bpw, heavy_cap, cs.off); fflush(stderr); }
     HIP_TRY(hipEventRecord(ctx->ev[0], st));
     HIP_TRY(hipMemsetAsync(counts, 0, (size_t)W * nb * 4, st));
     HIP_TRY(hipMemsetAsync(totals, 0, (size_t)(W + 1) * 4, st));
     k_digits<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_scalars, n, c, nwin, win_lo, win_hi, digits, counts);
+    DBG_SYNC("k_digits");
     k_scan<<<W, 1024, 0, st>>>(counts, offsets, cursor, totals, nb);
+    DBG_SYNC("k_scan");
     k_scatter<<<(unsigned)(((size_t)W * n + 255) / 256), 256, 0, st>>>(digits, cursor, sorted, n, W, nb);
+    DBG_SYNC("k_scatter");
     HIP_TRY(hipEventRecord(ctx->ev[2], st));
     k_accumulate<Cv><<<(unsigned)(((size_t)W * nseg + 127) / 128), 128, 0, st>>>(pts->d, off, sorted, offsets, counts, totals, buckets,
                                                                               edge_first, edge_last, n, nb, seg, nseg, W);
+    DBG_SYNC("k_accumulate");
     HIP_TRY(hipEventRecord(ctx->ev[3], st));
     k_fix<Cv><<<(unsigned)(((size_t)W * nb + 127) / 128), 128, 0, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list,
                                                                      heavy_count, W, nb, seg, nseg, heavy_cap);
+    DBG_SYNC("k_fix");
     const size_t sh_bytes = (size_t)256 * Cv::XW * 4;
     k_fix_heavy<Cv><<<512, 256, sh_bytes, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list, heavy_count, nb, seg, nseg, heavy_cap);
+    DBG_SYNC("k_fix_heavy");
     k_bucket_reduce<Cv><<<W * bpw, 256, sh_bytes, st>>>(buckets, partials, nb, L, bpw);
+    DBG_SYNC("k_bucket_reduce");
     k_window_finalize<Cv><<<(W + 63) / 64, 64, 0, st>>>(partials, wsums, W, bpw);
+    DBG_SYNC("k_window_finalize");
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev[1], st));
     HIP_TRY(hipMemcpyAsync(host_sums, wsums, (size_t)W * Cv::XW * 4, hipMemcpyDeviceToHost, st));
