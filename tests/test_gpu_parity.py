@@ -1,0 +1,230 @@
+"""Parity of the HIP path (through the C-ABI, include/dvn_prover.h) against the oracle.  Bit-exact everywhere:
+this is integer work.  MSM results are compared after affine normalisation."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+
+
+def aff1(orc, jac):
+    return orc.g1_jac_to_affine(jac)
+
+
+def aff2(orc, jac):
+    return orc.g2_jac_to_affine(jac)
+
+
+# ---- point sets -------------------------------------------------------------------------------------------------
+def test_points_roundtrip_and_synthetic(ctx, orc):
+    ph = orc.g1_synthetic_points(3, 300)
+    ph[7] = 0                                           # an infinity point survives the internal form
+    pu = ctx.upload_g1(ph)
+    assert len(pu) == 300 and (pu.download() == ph).all()
+    assert (pu.download(10, 5) == ph[10:15]).all()
+    pu.free()
+    for n in (1, 5, 1000):
+        ps = ctx.synthetic_g1(0xDA71C1, n)
+        assert (ps.download() == orc.g1_synthetic_points(0xDA71C1, n)).all()
+        ps.free()
+    p2 = ctx.synthetic_g2(7, 50)
+    assert (p2.download() == orc.g2_synthetic_points(7, 50)).all()
+    p2.free()
+
+
+# ---- MSM G1 -----------------------------------------------------------------------------------------------------
+def test_msm_g1_golden_vectors(ctx, orc, vectors, conv):
+    for case in vectors["msm_g1"]:
+        pts = ctx.upload_g1(conv.g1(case["points"]))
+        got = aff1(orc, ctx.msm_g1(pts, conv.fr(case["scalars"])))
+        assert (got == conv.g1([case["result"]])[0]).all(), case["name"]
+        pts.free()
+
+
+@pytest.mark.parametrize("n", [1, 2, 33, 1000, 1 << 12, (1 << 14) + 17, 1 << 16, 1 << 18])
+@pytest.mark.parametrize("kind", [0, 1])
+def test_msm_g1_vs_oracle(ctx, orc, n, kind):
+    ph = orc.g1_synthetic_points(0xDA71C1, n)
+    pts = ctx.upload_g1(ph)
+    sc = orc.scalars(1 + n, kind, n)
+    assert (aff1(orc, ctx.msm_g1(pts, sc)) == orc.msm_g1(ph, sc)).all()
+    pts.free()
+
+
+def test_msm_g1_offsets_subranges_and_device_scalars(ctx, orc):
+    n = 5000
+    ph = orc.g1_synthetic_points(11, n)
+    pts = ctx.upload_g1(ph)
+    sc = orc.scalars(5, 0, n)
+    for off, m in ((0, n), (17, 1000), (4999, 1), (1234, 3000)):
+        assert (aff1(orc, ctx.msm_g1(pts, sc[:m], off=off)) == orc.msm_g1(ph[off:off + m], sc[:m])).all()
+    d = ctx.to_device(sc)
+    assert (aff1(orc, ctx.msm_g1(pts, d, n=n)) == orc.msm_g1(ph, sc)).all()
+    ctx.free(d); pts.free()
+
+
+def test_msm_g1_empty_and_errors(ctx, orc, pkg):
+    ph = orc.g1_synthetic_points(11, 10)
+    pts = ctx.upload_g1(ph)
+    empty = ctx.msm_g1(pts, np.zeros((0, 4), dtype=np.uint64))
+    assert (aff1(orc, empty) == 0).all()                                   # infinity
+    with pytest.raises(pkg.DvnError) as e:                                 # MultiExp: len(points) != len(scalars)
+        ctx.msm_g1(pts, orc.scalars(1, 0, 11))
+    assert e.value.code == -1
+    p2 = ctx.upload_g2(orc.g2_synthetic_points(1, 4))
+    with pytest.raises(pkg.DvnError):
+        ctx.msm_g1(p2, orc.scalars(1, 0, 4))                               # wrong curve handle
+    p2.free(); pts.free()
+
+
+def test_msm_g1_hot_bucket_skew(ctx, orc):
+    """All scalars equal (every entry of every window in one bucket) and all ones: the heavy-bucket path."""
+    n = 1 << 15
+    ph = orc.g1_synthetic_points(21, n)
+    pts = ctx.upload_g1(ph)
+    one = orc.scalars(1, 0, 1)
+    for sc in (np.repeat(one, n, axis=0), np.repeat(orc.scalars(1, 1, 2000)[-1:], n, axis=0)):
+        assert (aff1(orc, ctx.msm_g1(pts, sc)) == orc.msm_g1(ph, sc)).all()
+    pts.free()
+
+
+def test_msm_g1_linearity_and_window_sharding(ctx, orc, opy):
+    n = 3000
+    ph = orc.g1_synthetic_points(31, n)
+    pts = ctx.upload_g1(ph)
+    a, b = orc.scalars(1, 0, n), orc.scalars(2, 0, n)
+    ab = np.array([orc.fr_add(a[i], b[i]) for i in range(n)], dtype=np.uint64)
+    ra, rb, rab = (aff1(orc, ctx.msm_g1(pts, s)) for s in (a, b, ab))
+    assert (orc.g1_add(ra, rb) == rab).all()
+    # window-sharded evaluation: any split of the windows recombines to the same point
+    c, nwin = ctx.msm_plan(n)
+    for cuts in ([0, nwin], [0, nwin // 2, nwin], [0, 1, 5, nwin]):
+        parts = [ctx.msm_g1_windows(pts, a, lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:])]
+        got = aff1(orc, ctx.msm_combine_g1(np.concatenate(parts), c))
+        assert (got == ra).all()
+    pts.free()
+
+
+@pytest.mark.parametrize("log_n", [20, 22])
+def test_msm_g1_full_size_closed_form(ctx, orc, opy, log_n):
+    """BASELINE sizes: MSM over P_i = P0 + i D equals (sum s_i) P0 + (sum i s_i) D, computed independently."""
+    o = opy
+    n = 1 << log_n
+    pts = ctx.synthetic_g1(0xDA71C1, n)
+    two = pts.download(0, 2)
+    assert (two == orc.g1_synthetic_points(0xDA71C1, 2)).all()
+    tail = pts.download(n - 3, 3)
+    p0 = o.g1_from_limbs([int(v) for v in two[0]]); p1 = o.g1_from_limbs([int(v) for v in two[1]])
+    d = o.g1_add(p1, o.g1_neg(p0))
+    assert list(tail[2]) == o.g1_to_limbs(o.g1_add(p0, o.g1_mul(d, n - 1)))        # spot-check the generator
+    for kind in (0, 1):
+        sc = orc.scalars(1, kind, n)
+        can = orc.fr_vec_from_mont(sc).astype(object)
+        vals = can[:, 0] + (can[:, 1] << 64) + (can[:, 2] << 128) + (can[:, 3] << 192)
+        s0 = int(vals.sum()) % R
+        s1 = int((vals * np.arange(n, dtype=object)).sum()) % R
+        want = o.g1_add(o.g1_mul(p0, s0), o.g1_mul(d, s1))
+        assert list(aff1(orc, ctx.msm_g1(pts, sc))) == o.g1_to_limbs(want)
+    pts.free()
+
+
+# ---- MSM G2 -----------------------------------------------------------------------------------------------------
+def test_msm_g2_golden_vectors(ctx, orc, vectors, conv):
+    for case in vectors["msm_g2"]:
+        pts = ctx.upload_g2(conv.g2(case["points"]))
+        got = aff2(orc, ctx.msm_g2(pts, conv.fr(case["scalars"])))
+        assert (got == conv.g2([case["result"]])[0]).all(), case["name"]
+        pts.free()
+
+
+@pytest.mark.parametrize("n", [1, 17, 1000, 1 << 13])
+def test_msm_g2_vs_oracle(ctx, orc, n):
+    ph = orc.g2_synthetic_points(5, n)
+    pts = ctx.upload_g2(ph)
+    for kind in (0, 1):
+        sc = orc.scalars(9, kind, n)
+        assert (aff2(orc, ctx.msm_g2(pts, sc)) == orc.msm_g2(ph, sc)).all()
+    pts.free()
+
+
+# ---- NTT ----------------------------------------------------------------------------------------------------------
+def test_ntt_golden_vectors(ctx, vectors, conv):
+    doms = {}
+    for case in vectors["ntt"]:
+        dom = doms.setdefault(case["log_n"], ctx.domain(case["log_n"]))
+        x = conv.fr(case["input"])
+        ctx.ntt(dom, x, bool(case["inverse"]), case["decimation"], bool(case["coset"]))
+        assert (x == conv.fr(case["output"])).all(), {k: case[k] for k in ("log_n", "inverse", "decimation", "coset")}
+    for d in doms.values():
+        d.free()
+
+
+@pytest.mark.parametrize("log_n", [1, 2, 3, 5, 8, 9, 11, 12, 16, 17, 19])
+def test_ntt_all_modes_vs_oracle(ctx, orc, log_n):
+    n = 1 << log_n
+    dom = ctx.domain(log_n)
+    x = orc.scalars(2, 0, n)
+    for inv in (False, True):
+        for dec in (0, 1):
+            for cos in (False, True):
+                y = x.copy()
+                ctx.ntt(dom, y, inv, dec, cos)
+                assert (y == orc.ntt(x, inv, dec, cos)).all(), (log_n, inv, dec, cos)
+    dom.free()
+
+
+def test_ntt_full_size_properties(ctx, orc, pkg):
+    """2^24 (BASELINE config 3): device-resident round trips in every pairing + linearity, no CPU transform."""
+    log_n = 24
+    n = 1 << log_n
+    dom = ctx.domain(log_n)
+    x = orc.scalars(2, 0, n)
+    dx = ctx.to_device(x)
+    y = np.empty_like(x)
+    for cos in (False, True):
+        ctx.ntt(dom, dx, False, pkg.DIF, cos); ctx.ntt(dom, dx, True, pkg.DIT, cos)
+        ctx.d2h(y, dx); assert (y == x).all()
+        ctx.ntt(dom, dx, True, pkg.DIF, cos); ctx.ntt(dom, dx, False, pkg.DIT, cos)
+        ctx.d2h(y, dx); assert (y == x).all()
+    # a delta at index 1 transforms (DIF, bit-reversed output) to the powers of the generator: y[rev(k)] = w^k
+    delta = np.zeros_like(x); delta[1] = orc.fr_to_mont(np.array([1, 0, 0, 0], dtype=np.uint64))
+    ctx.h2d(dx, delta); ctx.ntt(dom, dx, False, pkg.DIF, False); ctx.d2h(y, dx)
+    w = orc.ntt(np.array([[0, 0, 0, 0], delta[1]], dtype=np.uint64), False, 0, False)     # placeholder shape check
+    assert w.shape == (2, 4)
+    one = delta[1]
+    assert (y[0] == one).all()                                    # w^0
+    half = y[1]                                                   # rev(1<<23)=1 -> w^(n/2) = -1
+    assert (orc.fr_add(half, one) == 0).all()
+    quarter = y[2]                                                # rev(2) = n/4 -> w^(n/4), a 4th root of unity
+    assert (orc.fr_mul(quarter, quarter) == half).all()
+    ctx.free(dx); dom.free()
+
+
+# ---- computeH --------------------------------------------------------------------------------------------------
+def test_compute_h_golden_vectors(ctx, vectors, conv):
+    for case in vectors["compute_h"]:
+        dom = ctx.domain(case["log_n"])
+        h = ctx.compute_h(dom, conv.fr(case["a"]), conv.fr(case["b"]), conv.fr(case["c"]))
+        assert (h == conv.fr(case["h"])).all()
+        dom.free()
+
+
+@pytest.mark.parametrize("log_n,m", [(3, 5), (10, 1000), (16, (1 << 16) - 3), (18, 1 << 18)])
+def test_compute_h_vs_oracle(ctx, orc, log_n, m):
+    dom = ctx.domain(log_n)
+    a, b, c = orc.scalars(3, 0, m), orc.scalars(4, 0, m), orc.scalars(5, 0, m)
+    assert (ctx.compute_h(dom, a, b, c) == orc.compute_h(a, b, c, log_n)).all()
+    dom.free()
+
+
+def test_compute_h_rejects_oversized_input(ctx, orc, pkg):
+    dom = ctx.domain(4)
+    a = orc.scalars(3, 0, 17)
+    with pytest.raises(pkg.DvnError):
+        ctx.compute_h(dom, a, a, a)
+    dom.free()
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+    g.smoke()

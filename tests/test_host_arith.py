@@ -1,0 +1,77 @@
+"""The device arithmetic headers (9x29-bit Montgomery field, XYZZ group law), compiled for the host with g++
+(csrc/libdvn_hostcheck.so) and checked against the oracle: the same code the HIP kernels run, minus the GPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "davinci-node_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def hc():
+    subprocess.check_call(["make", "-C", CSRC, "-s", "libdvn_hostcheck.so"])
+    return C.CDLL(os.path.join(CSRC, "libdvn_hostcheck.so"))
+
+
+def p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+@pytest.mark.parametrize("field", ["fp", "fr"])
+def test_field_ops(hc, opy, field):
+    o = opy
+    mod = o.P if field == "fp" else o.R
+    fn = hc.hc_fp_op if field == "fp" else hc.hc_fr_op
+    L = lambda x: np.array(o.limbs(x), dtype=np.uint64)
+    V = lambda a: o.from_limbs(a)
+    rng = o.SplitMix64(5)
+    specials = [(0, 0), (0, 1), (mod - 1, mod - 1), (1, mod - 1), (mod - 1, 1), (2, mod - 2), ((1 << 253) % mod, (1 << 252) % mod)]
+    for it in range(2000):
+        a, b = specials[it] if it < len(specials) else (rng.next_fr() * 3 % mod, rng.next_fr() * 5 % mod)
+        am, bm, r = L(o.to_mont(a, mod)), L(o.to_mont(b, mod)), np.zeros(4, dtype=np.uint64)
+        exp = {0: a * b % mod, 1: (a + b) % mod, 2: (a - b) % mod, 3: a * a % mod, 5: (-a) % mod, 6: 2 * a % mod}
+        for op, want in exp.items():
+            fn(p(am), p(bm), p(r), op)
+            assert V(r) == o.to_mont(want, mod), (field, op, hex(a), hex(b))
+        if it < 12:
+            fn(p(am), p(bm), p(r), 4)
+            assert V(r) == o.to_mont(pow(a, -1, mod) if a else 0, mod)
+        if field == "fr":
+            hc.hc_fr_ext_to_canonical(p(am), p(r)); assert V(r) == a
+        hc.hc_pack_roundtrip(p(am), p(r)); assert V(r) == V(am)
+        assert hc.hc_fp_is_zero_of_diff(p(am), p(am)) == 1
+
+
+def test_group_law_edge_cases(hc, opy, orc):
+    o = opy
+    pts = orc.g1_synthetic_points(9, 8)
+    inf = np.zeros(8, dtype=np.uint64)
+    neg = lambda pt: np.array(o.g1_to_limbs(o.g1_neg(o.g1_from_limbs([int(v) for v in pt]))), dtype=np.uint64)
+    cases = [(pts[0], pts[1]), (pts[0], pts[0]), (pts[0], neg(pts[0])), (inf, pts[2]), (pts[2], inf), (inf, inf)]
+    for a, b in cases:
+        r = np.zeros(8, dtype=np.uint64)
+        want = orc.g1_add(a, b)
+        hc.hc_g1_add(p(a), p(b), p(r)); assert (r == want).all()
+        hc.hc_g1_add_full(p(a), p(b), p(r)); assert (r == want).all()
+    pts2 = orc.g2_synthetic_points(4, 3)
+    r2 = np.zeros(16, dtype=np.uint64)
+    for a, b in ((pts2[0], pts2[1]), (pts2[0], pts2[0])):
+        hc.hc_g2_add(p(a), p(b), p(r2)); assert (r2 == orc.g2_add(a, b)).all()
+
+
+def test_naive_msm_through_device_group_law(hc, opy, orc):
+    o = opy
+    pts = orc.g1_synthetic_points(9, 8)
+    sc = [o.fr_at(3, i) for i in range(8)]; sc[3] = 0; sc[4] = 1; sc[5] = o.R - 1
+    k = np.array([o.limbs(s) for s in sc], dtype=np.uint64)
+    km = np.array([o.limbs(o.to_mont(s, o.R)) for s in sc], dtype=np.uint64)
+    r = np.zeros(8, dtype=np.uint64)
+    hc.hc_g1_msm_naive(p(pts), p(k), C.c_size_t(8), p(r))
+    assert (r == orc.msm_g1(pts, km)).all()
+    pts2 = orc.g2_synthetic_points(4, 5)
+    r2 = np.zeros(16, dtype=np.uint64)
+    hc.hc_g2_msm_naive(p(pts2), p(k), C.c_size_t(5), p(r2))
+    assert (r2 == orc.msm_g2(pts2, km[:5])).all()
