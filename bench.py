@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- BN254 G1 MSM throughput on MI355X through the C-ABI (include/dvn_prover.h).
+
+Metric (BASELINE.json): "BN254 G1 MSM Mscalar/s @2^22".  One step = one 2^22-point MultiExp (gnark-crypto
+G1Jac.MultiExp semantics) with points AND scalars already resident in HBM.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+N > 1: the MSM is sharded by Pippenger window: every rank holds the whole point set and scalar
+vector, accumulates its slice of the windows, the per-window sums (<= 2 KiB) are exchanged with one RCCL
+all-gather, and every rank finishes with the host Horner combine.  Total work is fixed -> "scaling": "strong".
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (k_accumulate): algorithmic bytes =
+96 B per (scalar, point) pair x pairs per launch, divided by that kernel's mean launch duration
+measured with HIP events on the library's stream.  `cpu_baseline` is the C oracle (own Pippenger, NOT gnark)
+timed on this host's cores over a bounded sample.
+"""
+from __future__ import annotations
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+BYTES_PER_PAIR = 96            # 32 B scalar + 64 B affine point, SURVEY.md §8d
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log-n", type=int, default=22)
+    ap.add_argument("--scalars", choices=["uniform", "witness"], default="uniform")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-log-n", type=int, default=20)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch
+    import __graft_entry__ as g
+    pkg = g.load_package()                      # raises if libdvn_prover.so is missing: no fallback
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ctx = pkg.Context(local_rank)
+
+    n = 1 << args.log_n
+    c, nwin = ctx.msm_plan(n)
+
+    # ---- inputs resident in HBM before the timed region (generated ON the device by the library) -------------
+    kind = 0 if args.scalars == "uniform" else 1
+    pts = ctx.synthetic_g1(0xDA71C1, n)                                  # synthetic SRS  P_i = P0 + i*D
+    scal_dev = ctx.synthetic_scalars(1, kind, n)                         # n x 32 B Montgomery scalars in HBM
+
+    from davinci_node_amd import sharding
+
+    acc_ms = []
+    dev_ms = []
+
+    def step():
+        if world == 1:
+            out = ctx.msm_g1(pts, scal_dev, n=n)
+        else:
+            out = sharding.sharded_msm_g1(ctx, pts, scal_dev, n, rank, world, dist, "cuda")
+        acc_ms.append(ctx.last_kernel_ms(1)); dev_ms.append(ctx.last_kernel_ms(0))
+        return out
+
+    def sync():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    result = None
+    for _ in range(args.warmup):
+        result = step()
+    acc_ms.clear(); dev_ms.clear()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- self-consistency of what was timed (library only, size-independent): over the arithmetic progression
+    # P_i = P0 + i*D,  sum s_i P_i = (S0 - S1) P0 + S1 P1  with S0 = sum s_i, S1 = sum i*s_i  -- a 2-point MSM that
+    # runs with a different window size (c = 6, 43 windows) than the 2^22 one (c = 16, 16 windows).
+    check = None
+    if rank == 0:
+        R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+        sm = np.empty((n, 4), dtype=np.uint64); ctx.d2h(sm, scal_dev)
+        so = sm.astype(object)
+        vals = so[:, 0] + (so[:, 1] << 64) + (so[:, 2] << 128) + (so[:, 3] << 192)       # Montgomery images x*2^256
+        rinv = pow(1 << 256, -1, R)
+        S0 = int(vals.sum()) * rinv % R
+        S1 = int((vals * np.arange(n, dtype=object)).sum()) * rinv % R
+        to_m = lambda x: [((x << 256) % R >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)]
+        two = ctx.upload_g1(pts.download(0, 2))
+        small = ctx.msm_g1(two, np.array([to_m((S0 - S1) % R), to_m(S1)], dtype=np.uint64))
+        check = bool((small == result).all())
+        two.free()
+
+    # ---- CPU baseline leg (rank 0, N = 1 only): the oracle, timed on a bounded sample, also checks the GPU there -
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import cpu as orc              # test infrastructure: used here only as baseline + checker
+        m = 1 << min(args.cpu_sample_log_n, args.log_n)
+        ph = pts.download(0, m)
+        sh = np.ascontiguousarray(sm[:m])
+        t0 = time.perf_counter()
+        want = orc.msm_g1(ph, sh)
+        dt = time.perf_counter() - t0
+        got = orc.g1_jac_to_affine(ctx.msm_g1(pts, sh))
+        cpu = {"value": round(m / dt / 1e6, 4), "unit": "Mscalar/s", "cores": orc.num_threads(), "kind": "port",
+               "sample": f"one G1 MSM over the first 2^{m.bit_length() - 1} points/scalars of the same workload, "
+                         f"{dt:.2f} s wall; own C Pippenger (oracle/bn254_cpu.c), not gnark",
+               "gpu_matches_on_sample": bool((got == want).all())}
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = n * args.steps / elapsed / 1e6
+        pairs_per_launch = n                         # k_accumulate consumes every (scalar, point) pair once per launch
+        acc = float(np.mean(acc_ms))
+        achieved = BYTES_PER_PAIR * pairs_per_launch / (acc * 1e-3) / 1e9
+        out = {
+            "metric": "BN254 G1 MSM throughput @2^%d" % args.log_n, "value": round(value, 3), "unit": "Mscalar/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u32 (9x29-bit limbs, v_mad_u64_u32)", "data": "synthetic",
+            "config": {"workload": f"bn254_g1_msm_2^{args.log_n}_{args.scalars}_scalars", "points": n,
+                       "window_bits": c, "windows": nwin, "parallelism": "1 GPU" if world == 1 else f"window-sharded x{world}, RCCL all-gather",
+                       "inputs": "points + scalars resident in HBM", "result_checked": check},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "kernel": "k_accumulate<G1>", "kernel_ms": round(acc, 4), "device_ms_per_step": round(float(np.mean(dev_ms)), 4)},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.free(scal_dev)
+    pts.free()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -8,6 +8,7 @@ is NO CPU fallback: if the HIP library is missing or no GPU is visible, calls ra
 The directory name contains a dash, so import it through ``__graft_entry__.load_package()`` (or
 ``importlib``) under the module name ``davinci_node_amd``.
 """
+from . import sharding  # noqa: F401
 from .binding import (  # noqa: F401
     DvnError, Context, Points, Domain, lib_path, load_library, build_library,
     DIF, DIT,

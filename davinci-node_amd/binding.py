@@ -57,6 +57,7 @@ def load_library():
         "dvn_points_upload_g2": (i32, [vp, vp, sz, C.POINTER(vp)]),
         "dvn_points_synthetic_g1": (i32, [vp, u64, sz, C.POINTER(vp)]),
         "dvn_points_synthetic_g2": (i32, [vp, u64, sz, C.POINTER(vp)]),
+        "dvn_scalars_synthetic": (i32, [vp, u64, C.c_int, sz, vp]),
         "dvn_points_download": (i32, [vp, vp, sz, sz, vp]),
         "dvn_points_len": (sz, [vp]),
         "dvn_points_free": (i32, [vp, vp]),
@@ -82,7 +83,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "dvn_init", "dvn_shutdown", "dvn_last_error", "dvn_version", "dvn_malloc", "dvn_free", "dvn_memcpy_h2d",
     "dvn_memcpy_d2h", "dvn_synchronize", "dvn_points_upload_g1", "dvn_points_upload_g2", "dvn_points_synthetic_g1",
-    "dvn_points_synthetic_g2", "dvn_points_download", "dvn_points_len", "dvn_points_free", "dvn_msm_g1", "dvn_msm_g2",
+    "dvn_points_synthetic_g2", "dvn_scalars_synthetic", "dvn_points_download", "dvn_points_len", "dvn_points_free", "dvn_msm_g1", "dvn_msm_g2",
     "dvn_msm_plan", "dvn_msm_g1_windows", "dvn_msm_combine_g1", "dvn_ntt_domain", "dvn_ntt_domain_free", "dvn_ntt",
     "dvn_groth16_compute_h", "dvn_last_kernel_ms",
 ]
@@ -180,6 +181,12 @@ class Context:
 
     def synthetic_g2(self, seed: int, n: int) -> Points:
         p = C.c_void_p(); self._chk(self.L.dvn_points_synthetic_g2(self.h, seed, n, C.byref(p))); return Points(self, p, 2)
+
+    def synthetic_scalars(self, seed: int, kind: int, n: int) -> int:
+        """Device-resident synthetic scalar vector (n x 32 B); returns the device pointer (free with ctx.free)."""
+        d = self.malloc(n * 32)
+        self._chk(self.L.dvn_scalars_synthetic(self.h, seed, kind, n, C.c_void_p(d)))
+        return d
 
     # ---- MSM.  scalars: (n,4) uint64 host array, or an int device pointer with n given.
     def _scalars(self, scalars, n):

@@ -36,7 +36,8 @@ extern "C" int32_t dvn_msm_g1_windows(dvn_ctx* ctx, const dvn_points* pts, size_
 }
 
 extern "C" int32_t dvn_msm_combine_g1(dvn_ctx* ctx, const uint64_t* window_sums, uint32_t nwin, uint32_t window_bits, uint64_t out_jac[12]) {
-    if (!ctx || !window_sums || !out_jac) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    (void)ctx;   /* pure host computation: ctx may be NULL (CPU-side tests of the sharded path) */
+    if (!window_sums || !out_jac) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (window_bits == 0 || window_bits > 16 || nwin == 0 || nwin > 64) return fail(DVN_ERR_INVALID_ARG, "bad window layout");
     const u32* in = (const u32*)window_sums;
     std::vector<u32> sums((size_t)nwin * G1::XW);
@@ -74,5 +75,17 @@ extern "C" int32_t dvn_points_download(dvn_ctx* ctx, const dvn_points* pts, size
 extern "C" int32_t dvn_msm_plan(size_t n, uint32_t* window_bits, uint32_t* nwin) {
     if (!window_bits || !nwin) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     msm_plan(n, window_bits, nwin);
+    return DVN_OK;
+}
+
+extern "C" int32_t dvn_scalars_synthetic(dvn_ctx* ctx, uint64_t seed, int kind, size_t n, void* d_out) {
+    TRY(enter(ctx));
+    if (!d_out && n) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    if (kind != 0 && kind != 1) return fail(DVN_ERR_INVALID_ARG, "kind must be 0 (uniform) or 1 (witness-like)");
+    if (n == 0) return DVN_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    k_scalars_synthetic<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>((u32*)d_out, n, seed, kind);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return DVN_OK;
 }

@@ -92,6 +92,42 @@ template <class Cv> __global__ void k_points_progression(u32* __restrict__ pts, 
     }
 }
 
+// ---- synthetic scalar streams (bench/test inputs; oracle/bn254_py.py fr_at / witness_like_scalar) -----------
+__device__ __forceinline__ u64 dev_splitmix_at(u64 seed, u64 index) {
+    u64 z = seed + (index + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+// kind 0: uniform mod r; kind 1: 40 % zero, 25 % one, 25 % < 2^64, 10 % uniform.  Output gnark Montgomery words.
+static __global__ void k_scalars_synthetic(u32* __restrict__ out, size_t n, u64 seed, int kind) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int mode = 3;   // 0 zero, 1 one, 2 one word, 3 full
+    if (kind == 1) {
+        const u64 sel = dev_splitmix_at(seed ^ 0x5EED5EED5EED5EEDULL, i) % 100;
+        mode = sel < 40 ? 0 : sel < 65 ? 1 : sel < 90 ? 2 : 3;
+    }
+    if (mode == 1) w[0] = 1;
+    else if (mode == 2) { u64 v = dev_splitmix_at(seed, 4 * i); w[0] = (u32)v; w[1] = (u32)(v >> 32); }
+    else if (mode == 3) {
+        for (int k = 0; k < 4; ++k) { u64 v = dev_splitmix_at(seed, 4 * i + k); w[2 * k] = (u32)v; w[2 * k + 1] = (u32)(v >> 32); }
+        // reduce the 256-bit value mod r (< 6r): repeated conditional subtraction
+        const u32 rm[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+        for (int rep = 0; rep < 6; ++rep) {
+            bool ge = true;
+            for (int j = 7; j >= 0; --j) { if (w[j] > rm[j]) { ge = true; break; } if (w[j] < rm[j]) { ge = false; break; } }
+            if (!ge) break;
+            u64 br = 0;
+            for (int j = 0; j < 8; ++j) { u64 d = (u64)w[j] - rm[j] - br; w[j] = (u32)d; br = (d >> 32) & 1; }
+        }
+    }
+    u32 o[8];
+    fe_to_ext_mont<FrCfg>(fe_from_canonical<FrCfg>(fe_unpack<FrCfg>(w)), o);
+    store_words16(out + i * 8, o, 8);
+}
+
 // ---- digits + histogram ----------------------------------------------------------------------------------
 // digits[(w - win_lo) * n + i] = magnitude | sign<<31 (0 = skip).  counts[(w - win_lo) * nb + magnitude-1]++
 static __global__ void k_digits(const u32* __restrict__ scalars, size_t n, u32 c, u32 nwin, u32 win_lo, u32 win_hi,

@@ -1,0 +1,45 @@
+"""Window-sharded MSM across the GPUs of one node (BASELINE.json north_star).
+
+Every rank holds the whole device-resident point set and scalar vector, accumulates a contiguous slice of the
+Pippenger windows and reduces each to one point; the exchange is ONE all-gather of `ceil(nwin/world) x 128 B`
+per rank (RCCL over xGMI with backend "nccl", gloo in the CPU tests) -- RCCL has no elliptic-curve reduction
+operator, so the "all-reduce of partial bucket sums" is all-gather of bytes + the local Horner combine
+(dvn_msm_combine_g1).  At <= 2 KiB total the step is latency-bound, never link-bound.
+"""
+from __future__ import annotations
+import numpy as np
+
+
+def window_slice(nwin: int, world: int, rank: int) -> tuple[int, int]:
+    """Contiguous, as-even-as-possible slice [lo, hi) of the nwin windows owned by `rank`."""
+    return rank * nwin // world, (rank + 1) * nwin // world
+
+
+def exchange_window_sums(local: np.ndarray, nwin: int, world: int, rank: int, dist=None, device="cpu") -> np.ndarray:
+    """all-gather the per-window sums.  local: (hi-lo, 16) uint64 for this rank's slice.  Returns (nwin, 16)."""
+    import torch
+    lo, hi = window_slice(nwin, world, rank)
+    assert local.shape == (hi - lo, 16), (local.shape, lo, hi)
+    if world == 1:
+        return local
+    per = -(-nwin // world)                                   # ranks own unequal counts when nwin % world != 0: pad
+    mine = np.zeros((per, 16), dtype=np.uint64)
+    mine[: hi - lo] = local
+    send = torch.from_numpy(mine.view(np.int64)).to(device)
+    recv = torch.empty((world * per, 16), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(recv, send)
+    allr = recv.cpu().numpy().view(np.uint64).reshape(world, per, 16)
+    out = np.zeros((nwin, 16), dtype=np.uint64)
+    for r in range(world):
+        l, h = window_slice(nwin, world, r)
+        out[l:h] = allr[r, : h - l]
+    return out
+
+
+def sharded_msm_g1(ctx, pts, scalars, n: int, rank: int, world: int, dist=None, device="cuda") -> np.ndarray:
+    """One window-sharded G1 MultiExp; every rank returns the same G1Jac image.  Returns (result, device_ms, kernel_ms)."""
+    c, nwin = ctx.msm_plan(n)
+    lo, hi = window_slice(nwin, world, rank)
+    sums = ctx.msm_g1_windows(pts, scalars, lo, hi, n=n)
+    allsums = exchange_window_sums(sums, nwin, world, rank, dist, device)
+    return ctx.msm_combine_g1(allsums, c)

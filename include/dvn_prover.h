@@ -62,6 +62,10 @@ int32_t dvn_points_upload_g2(dvn_ctx* ctx, const uint64_t* xy_mont, size_t n, dv
  * SplitMix64 stream `seed`.  Bench/test input generator. */
 int32_t dvn_points_synthetic_g1(dvn_ctx* ctx, uint64_t seed, size_t n, dvn_points** out);
 int32_t dvn_points_synthetic_g2(dvn_ctx* ctx, uint64_t seed, size_t n, dvn_points** out);
+/* Synthetic scalar vector written to DEVICE memory d_out (n x 4 uint64, gnark Montgomery form): kind 0 =
+ * uniform mod r from SplitMix64 stream `seed`, kind 1 = the witness-like mixture of SURVEY.md §8d (40 % zero,
+ * 25 % one, 25 % < 2^64, 10 % uniform).  Bench/test input generator. */
+int32_t dvn_scalars_synthetic(dvn_ctx* ctx, uint64_t seed, int kind, size_t n, void* d_out);
 /* Copy points [off, off+n) back to the host in gnark's affine Montgomery image. */
 int32_t dvn_points_download(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, uint64_t* xy_mont);
 size_t dvn_points_len(const dvn_points* pts);

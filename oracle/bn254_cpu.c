@@ -180,6 +180,22 @@ int orc_msm_g1(const u64* points, size_t n_points, const u64* scalars_mont, size
     free(canon);
     return 0;
 }
+/* per-window sums of the signed-digit Pippenger with window size c: out = (254/c + 1) x 16 u64, extended
+ * Jacobian (X, Y, ZZ, ZZZ) Montgomery, infinity = all zero.  Used to test the window-sharded multi-GPU path. */
+int orc_msm_g1_window_sums(const u64* points, const u64* scalars_mont, size_t n, int c, int nthreads, u64* out) {
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+    int nwin = 254 / c + 1;
+    u64* canon = (u64*)malloc(32 * (n ? n : 1));
+    orc_fr_vec_from_mont(scalars_mont, canon, n);
+    g1_xyzz r; g1_xyzz* ws = (g1_xyzz*)calloc(nwin, sizeof(g1_xyzz));
+    for (int w = 0; w < nwin; ++w) g1_xyzz_set_inf(&ws[w]);
+    g1_msm_ex(&r, (const g1_aff*)points, canon, n, nthreads, c, ws);
+    for (int w = 0; w < nwin; ++w) {
+        if (g1_xyzz_is_inf(&ws[w])) memset(out + 16 * w, 0, 128); else memcpy(out + 16 * w, &ws[w], 128);
+    }
+    free(ws); free(canon);
+    return nwin;
+}
 int orc_msm_g2(const u64* points, size_t n_points, const u64* scalars_mont, size_t n_scalars, int nthreads, u64* out16) {
     if (n_points != n_scalars) return -1;
     if (nthreads <= 0) nthreads = omp_get_max_threads();

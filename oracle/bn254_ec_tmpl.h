@@ -133,10 +133,12 @@ static int ECN(pippenger_c)(size_t n) {
     return best;
 }
 
-static void ECN(msm)(ECN(xyzz)* result, const ECN(aff)* points, const u64* scalars /* n x 4 canonical */, size_t n, int nthreads) {
+/* c_override > 0 forces the window size; wsum_out (optional) receives the per-window sums, 254/c + 1 of them */
+static void ECN(msm_ex)(ECN(xyzz)* result, const ECN(aff)* points, const u64* scalars /* n x 4 canonical */, size_t n, int nthreads,
+                        int c_override, ECN(xyzz)* wsum_out) {
     ECN(xyzz_set_inf)(result);
     if (n == 0) return;
-    const int c = ECN(pippenger_c)(n);
+    const int c = c_override > 0 ? c_override : ECN(pippenger_c)(n);
     const int nwin = 254 / c + 1;                 /* +1 absorbs the final signed-digit carry */
     const size_t nb = (size_t)1 << (c - 1);
     /* signed digits: digits[w*n + i] in [-2^(c-1), 2^(c-1)] */
@@ -184,7 +186,11 @@ static void ECN(msm)(ECN(xyzz)* result, const ECN(aff)* points, const u64* scala
         ECN(xyzz_add)(&acc, &wsum[w]);
     }
     *result = acc;
+    if (wsum_out) memcpy(wsum_out, wsum, sizeof(ECN(xyzz)) * nwin);
     free(wsum); free(digits);
+}
+static void ECN(msm)(ECN(xyzz)* result, const ECN(aff)* points, const u64* scalars, size_t n, int nthreads) {
+    ECN(msm_ex)(result, points, scalars, n, nthreads, 0, NULL);
 }
 
 /* out[i] = base + i*step (affine), i in [0, n): chunked mixed adds + batch normalisation */

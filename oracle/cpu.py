@@ -112,6 +112,14 @@ def msm_g1(points: np.ndarray, scalars_mont: np.ndarray, nthreads: int = 0) -> n
     return out
 
 
+def msm_g1_window_sums(points: np.ndarray, scalars_mont: np.ndarray, c: int, nthreads: int = 0) -> np.ndarray:
+    points = np.ascontiguousarray(points, dtype=np.uint64); scalars_mont = np.ascontiguousarray(scalars_mont, dtype=np.uint64)
+    nwin = 254 // c + 1
+    out = u64((nwin, 16))
+    lib().orc_msm_g1_window_sums(_p(points), _p(scalars_mont), C.c_size_t(points.shape[0]), c, nthreads, _p(out))
+    return out
+
+
 def msm_g2(points: np.ndarray, scalars_mont: np.ndarray, nthreads: int = 0) -> np.ndarray:
     points = np.ascontiguousarray(points, dtype=np.uint64); scalars_mont = np.ascontiguousarray(scalars_mont, dtype=np.uint64)
     out = u64(16)

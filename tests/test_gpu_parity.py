@@ -32,6 +32,14 @@ def test_points_roundtrip_and_synthetic(ctx, orc):
     p2.free()
 
 
+def test_synthetic_scalars_match_oracle_streams(ctx, orc):
+    for kind in (0, 1):
+        n = 5000
+        d = ctx.synthetic_scalars(1, kind, n)
+        got = np.empty((n, 4), dtype=np.uint64); ctx.d2h(got, d); ctx.free(d)
+        assert (got == orc.scalars(1, kind, n)).all()
+
+
 # ---- MSM G1 -----------------------------------------------------------------------------------------------------
 def test_msm_g1_golden_vectors(ctx, orc, vectors, conv):
     for case in vectors["msm_g1"]:

@@ -1,0 +1,90 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the window-sharded MSM exchange + combine.  The per-window
+sums come from the oracle here (no GPU in this container); the exchange and the Horner combine are the product
+code (davinci-node_amd/sharding.py, dvn_msm_combine_g1)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n, c, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    from oracle import cpu as orc
+    from davinci_node_amd import sharding, binding
+    import ctypes as C
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    pts = orc.g1_synthetic_points(0xDA71C1, n)
+    sc = orc.scalars(1, 0, n)
+    nwin = 254 // c + 1
+    lo, hi = sharding.window_slice(nwin, world, rank)
+    local = orc.msm_g1_window_sums(pts, sc, c)[lo:hi]                 # stands in for dvn_msm_g1_windows on this rank
+    allsums = sharding.exchange_window_sums(np.ascontiguousarray(local), nwin, world, rank, dist, "cpu")
+    L = pkg.load_library()
+    out = np.zeros(12, dtype=np.uint64)
+    rc = L.dvn_msm_combine_g1(None, C.c_void_p(allsums.ctypes.data), nwin, c, C.c_void_p(out.ctypes.data))
+    assert rc == 0
+    got = orc.g1_jac_to_affine(out)
+    want = orc.msm_g1(pts, sc)
+    q.put((rank, bool((got == want).all())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("c", [16, 13])          # 16 windows (even split) and 20 windows
+def test_window_sharded_msm_gloo_world2(c):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + c
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 3000, c, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_window_slices_cover_all_windows():
+    from __graft_entry__ import load_package
+    load_package()
+    from davinci_node_amd import sharding
+    for nwin in (16, 17, 20, 26, 43):
+        for world in (1, 2, 3, 4, 8):
+            cuts = [sharding.window_slice(nwin, world, r) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == nwin
+            assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+
+
+def test_exchange_with_uneven_slices_world3():
+    """Padding logic with nwin % world != 0, single process (simulated gather)."""
+    from __graft_entry__ import load_package
+    load_package()
+    from davinci_node_amd import sharding
+
+    class FakeDist:
+        def __init__(self, parts): self.parts = parts
+        def all_gather_into_tensor(self, recv, send):
+            import torch
+            recv.copy_(torch.cat(self.parts))
+
+    import torch
+    nwin, world = 20, 3
+    full = np.arange(nwin * 16, dtype=np.uint64).reshape(nwin, 16)
+    per = -(-nwin // world)
+    padded = []
+    for r in range(world):
+        lo, hi = sharding.window_slice(nwin, world, r)
+        m = np.zeros((per, 16), dtype=np.uint64); m[: hi - lo] = full[lo:hi]
+        padded.append(torch.from_numpy(m.view(np.int64)))
+    for r in range(world):
+        lo, hi = sharding.window_slice(nwin, world, r)
+        out = sharding.exchange_window_sums(np.ascontiguousarray(full[lo:hi]), nwin, world, r, FakeDist(padded), "cpu")
+        assert (out == full).all()
