@@ -101,15 +101,18 @@ static int32_t msm_windows(dvn_ctx* ctx, const dvn_points* pts, size_t off, size
     const u32 heavy_cap = (u32)(((size_t)W * nseg) / (FIX_LIGHT - 1) + 1);
     const bool on_dev = flags & DVN_MSM_SCALARS_ON_DEVICE;
 
+    const u32 tile_len = 65536;
+    const u32 ntiles = (u32)((n + tile_len - 1) / tile_len);
     CarverSize cs;
     if (!on_dev) cs.take(n * 32);
-    cs.take((size_t)W * n * 4); cs.take((size_t)W * n * 4);          // digits, sorted
-    cs.take((size_t)W * nb * 4 * 3); cs.take((size_t)W * 4 + 4);      // counts, offsets, cursor; totals + heavy_count
+    cs.take((size_t)W * n * 2); cs.take((size_t)W * n * 4);          // digits (int16), sorted
+    cs.take((size_t)W * ntiles * nb * 4);                             // per-tile histograms
+    cs.take((size_t)W * nb * 4 * 2); cs.take((size_t)W * 4 + 4);      // counts, offsets; totals + heavy_count
     cs.take((size_t)heavy_cap * 4);
     cs.take((size_t)W * nb * Cv::XW * 4);                             // bucket sums
     cs.take((size_t)W * nseg * Cv::XW * 4); cs.take((size_t)W * nseg * Cv::XW * 4);   // edges
     cs.take((size_t)W * bpw * Cv::XW * 4); cs.take((size_t)W * Cv::XW * 4);
-    TRY(ensure_ws(ctx, cs.off + 4096));
+    TRY(ensure_ws(ctx, cs.off + 8192));
     Carver cv(ctx->ws);
     const u32* d_scalars;
     if (!on_dev) {
@@ -117,11 +120,11 @@ static int32_t msm_windows(dvn_ctx* ctx, const dvn_points* pts, size_t off, size
         HIP_TRY(hipMemcpyAsync(tmp, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
         d_scalars = tmp;
     } else d_scalars = (const u32*)scalars;
-    u32* digits = cv.take<u32>((size_t)W * n);
+    int16_t* digits = cv.take<int16_t>((size_t)W * n);
     u32* sorted = cv.take<u32>((size_t)W * n);
-    u32* counts = cv.take<u32>((size_t)W * nb * 3);
+    u32* hist = cv.take<u32>((size_t)W * ntiles * nb);
+    u32* counts = cv.take<u32>((size_t)W * nb * 2);
     u32* offsets = counts + (size_t)W * nb;
-    u32* cursor = offsets + (size_t)W * nb;
     u32* totals = cv.take<u32>(W + 1);
     u32* heavy_count = totals + W;
     u32* heavy_list = cv.take<u32>(heavy_cap);
@@ -134,16 +137,26 @@ static int32_t msm_windows(dvn_ctx* ctx, const dvn_points* pts, size_t off, size
     hipStream_t st = ctx->stream;
     static const bool dbg = getenv("DVN_DEBUG_SYNC") != nullptr;
 #define DBG_SYNC(name) do { if (dbg) { hipError_t _e = hipStreamSynchronize(st); fprintf(stderr, "[dvn] %s: %s\n", name, hipGetErrorString(_e)); fflush(stderr); if (_e != hipSuccess) return fail(DVN_ERR_DEVICE, "%s: %s", name, hipGetErrorString(_e)); } } while (0)
-    if (dbg) { fprintf(stderr, "[dvn] msm n=%zu c=%u W=%u nb=%u seg=%u nseg=%u bpw=%u heavy_cap=%u ws=%zu\n", n, c, W, nb, seg, nseg, bpw, heavy_cap, cs.off); fflush(stderr); }
+    if (dbg) { fprintf(stderr, "[dvn] msm n=%zu c=%u W=%u nb=%u seg=%u nseg=%u bpw=%u ntiles=%u ws=%zu\n", n, c, W, nb, seg, nseg, bpw, ntiles, cs.off); fflush(stderr); }
+    const size_t hist_lds = (size_t)nb * 4;
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {   // 2^15 counters = 128 KiB of the CU's 160 KiB LDS: above the 64 KiB default cap
+        HIP_TRY(hipFuncSetAttribute((const void*)k_tile_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_tile_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        lds_attr_set = true;
+    }
     HIP_TRY(hipEventRecord(ctx->ev[0], st));
-    HIP_TRY(hipMemsetAsync(counts, 0, (size_t)W * nb * 4, st));
     HIP_TRY(hipMemsetAsync(totals, 0, (size_t)(W + 1) * 4, st));
-    k_digits<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_scalars, n, c, nwin, win_lo, win_hi, digits, counts);
-    DBG_SYNC("k_digits");
-    k_scan<<<W, 1024, 0, st>>>(counts, offsets, cursor, totals, nb);
+    k_digits16<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_scalars, n, c, win_lo, win_hi, digits);
+    DBG_SYNC("k_digits16");
+    k_tile_hist<<<W * ntiles, 1024, hist_lds, st>>>(digits, n, nb, tile_len, ntiles, hist);
+    DBG_SYNC("k_tile_hist");
+    k_tile_offsets<<<(unsigned)(((size_t)W * nb + 255) / 256), 256, 0, st>>>(hist, counts, nb, ntiles, W);
+    DBG_SYNC("k_tile_offsets");
+    k_scan<<<W, 1024, 0, st>>>(counts, offsets, totals, nb);
     DBG_SYNC("k_scan");
-    k_scatter<<<(unsigned)(((size_t)W * n + 255) / 256), 256, 0, st>>>(digits, cursor, sorted, n, W, nb);
-    DBG_SYNC("k_scatter");
+    k_tile_scatter<<<W * ntiles, 1024, hist_lds, st>>>(digits, n, nb, tile_len, ntiles, hist, offsets, sorted);
+    DBG_SYNC("k_tile_scatter");
     HIP_TRY(hipEventRecord(ctx->ev[2], st));
     k_accumulate<Cv><<<(unsigned)(((size_t)W * nseg + 127) / 128), 128, 0, st>>>(pts->d, off, sorted, offsets, counts, totals, buckets,
                                                                               edge_first, edge_last, n, nb, seg, nseg, W);

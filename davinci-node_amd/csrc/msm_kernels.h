@@ -4,9 +4,10 @@
 // five times per proof (/root/reference/prover/prover_cpu.go:37 -> gnark backend/groth16/bn254/prove.go).
 //
 // Pipeline (DESIGN.md "MSM"):
-//   k_digits      scalar (Montgomery) -> canonical -> signed c-bit digits for every window; per-bucket histogram
-//   k_scan        exclusive scan of the histogram per window
-//   k_scatter     counting sort of (point index | sign) by bucket, per window
+//   k_digits16    scalar (Montgomery) -> canonical -> signed c-bit digits (int16) for every window
+//   k_tile_hist / k_tile_offsets / k_scan / k_tile_scatter
+//                 per-window counting sort of (point index | sign) by bucket: 64K-entry tiles, the whole 2^(c-1)-
+//                 counter histogram of a tile lives in LDS (128 KiB at c = 16), every rank comes from an LDS atomic
 //   k_accumulate  HOT KERNEL: one lane per fixed-size SEGMENT of the sorted list (not per bucket), so every
 //                 lane of a wave does exactly SEG mixed additions whatever the scalar distribution is; runs
 //                 that a segment shares with its neighbours are written as edge partials
@@ -128,10 +129,11 @@ static __global__ void k_scalars_synthetic(u32* __restrict__ out, size_t n, u64 
     store_words16(out + i * 8, o, 8);
 }
 
-// ---- digits + histogram ----------------------------------------------------------------------------------
-// digits[(w - win_lo) * n + i] = magnitude | sign<<31 (0 = skip).  counts[(w - win_lo) * nb + magnitude-1]++
-static __global__ void k_digits(const u32* __restrict__ scalars, size_t n, u32 c, u32 nwin, u32 win_lo, u32 win_hi,
-                         u32* __restrict__ digits, u32* __restrict__ counts) {
+// ---- digits -> per-window counting sort, all ranking done with LDS atomics (no global atomics) ------------------
+// Signed c-bit digits in [-2^(c-1), 2^(c-1) - 1] stored as int16 (c <= 16): digits[(w - win_lo) * n + i].
+// Bucket index of a non-zero digit d is |d| - 1 in [0, 2^(c-1)).
+static __global__ void k_digits16(const u32* __restrict__ scalars, size_t n, u32 c, u32 win_lo, u32 win_hi,
+                                  int16_t* __restrict__ digits) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 w[8];
@@ -155,20 +157,63 @@ static __global__ void k_digits(const u32* __restrict__ scalars, size_t n, u32 c
             d += (u32)(two >> sh) & mask;
         }
         carry = 0;
-        u32 enc = 0;
-        if (d > nb) { d = (1u << c) - d; carry = 1; enc = d ? (d | SIGN_BIT) : 0; }
-        else enc = d;
-        if (win >= win_lo) {
-            digits[(size_t)(win - win_lo) * n + i] = enc;
-            if (enc) atomicAdd(&counts[(size_t)(win - win_lo) * nb + (enc & ~SIGN_BIT) - 1], 1u);
+        int v = (int)d;
+        if (d >= nb) { v = (int)d - (int)(1u << c); carry = 1; }
+        if (win >= win_lo) digits[(size_t)(win - win_lo) * n + i] = (int16_t)v;
+    }
+}
+
+// block (w, tile): histogram of the tile's bucket indices in LDS -> hist[(w * ntiles + tile) * nb + b]
+static __global__ __launch_bounds__(1024) void k_tile_hist(const int16_t* __restrict__ digits, size_t n, u32 nb, u32 tile_len,
+                                                           u32 ntiles, u32* __restrict__ hist) {
+    extern __shared__ __align__(16) u32 lh[];
+    const u32 w = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
+    for (u32 b = threadIdx.x; b < nb; b += blockDim.x) lh[b] = 0;
+    __syncthreads();
+    const size_t lo = (size_t)tile * tile_len, hi = min(lo + (size_t)tile_len, n);
+    const int16_t* dg = digits + (size_t)w * n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const int d = dg[i];
+        if (d) atomicAdd(&lh[(d < 0 ? -d : d) - 1], 1u);
+    }
+    __syncthreads();
+    u32* out = hist + (size_t)blockIdx.x * nb;
+    for (u32 b = threadIdx.x; b < nb; b += blockDim.x) out[b] = lh[b];
+}
+// thread (w, b): exclusive prefix of hist over the tiles of window w, in place; counts[w][b] = total
+static __global__ void k_tile_offsets(u32* __restrict__ hist, u32* __restrict__ counts, u32 nb, u32 ntiles, u32 nwin_local) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (size_t)nwin_local * nb) return;
+    const u32 w = (u32)(g / nb), b = (u32)(g % nb);
+    u32 run = 0;
+    u32* p = hist + (size_t)w * ntiles * nb + b;
+    for (u32 t = 0; t < ntiles; ++t, p += nb) { const u32 v = *p; *p = run; run += v; }
+    counts[g] = run;
+}
+// block (w, tile): final position of every entry = offsets[w][b] + hist[w][tile][b] + rank inside the tile
+static __global__ __launch_bounds__(1024) void k_tile_scatter(const int16_t* __restrict__ digits, size_t n, u32 nb, u32 tile_len,
+                                                              u32 ntiles, const u32* __restrict__ hist,
+                                                              const u32* __restrict__ offsets, u32* __restrict__ sorted) {
+    extern __shared__ __align__(16) u32 lh[];
+    const u32 w = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
+    const u32* hb = hist + (size_t)blockIdx.x * nb;
+    const u32* ob = offsets + (size_t)w * nb;
+    for (u32 b = threadIdx.x; b < nb; b += blockDim.x) lh[b] = hb[b] + ob[b];
+    __syncthreads();
+    const size_t lo = (size_t)tile * tile_len, hi = min(lo + (size_t)tile_len, n);
+    const int16_t* dg = digits + (size_t)w * n;
+    u32* dst = sorted + (size_t)w * n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const int d = dg[i];
+        if (d) {
+            const u32 pos = atomicAdd(&lh[(d < 0 ? -d : d) - 1], 1u);
+            dst[pos] = (u32)i | (d < 0 ? SIGN_BIT : 0u);
         }
     }
-    (void)nwin;
 }
 
 // one block per window: offsets = exclusive scan of counts; totals[w] = number of entries
-static __global__ void k_scan(const u32* __restrict__ counts, u32* __restrict__ offsets, u32* __restrict__ cursor,
-                       u32* __restrict__ totals, u32 nb) {
+static __global__ void k_scan(const u32* __restrict__ counts, u32* __restrict__ offsets, u32* __restrict__ totals, u32 nb) {
     __shared__ u32 part[1024];
     const u32 w = blockIdx.x, t = threadIdx.x, T = blockDim.x;
     const u32 per = (nb + T - 1) / T;
@@ -185,25 +230,8 @@ static __global__ void k_scan(const u32* __restrict__ counts, u32* __restrict__ 
         __syncthreads();
     }
     u32 run = part[t] - s;
-    for (u32 b = lo; b < hi; ++b) {
-        offsets[(size_t)w * nb + b] = run;
-        cursor[(size_t)w * nb + b] = run;
-        run += cw[b];
-    }
+    for (u32 b = lo; b < hi; ++b) { offsets[(size_t)w * nb + b] = run; run += cw[b]; }
     if (t == T - 1) totals[w] = part[t];
-}
-
-static __global__ void k_scatter(const u32* __restrict__ digits, u32* __restrict__ cursor, u32* __restrict__ sorted,
-                          size_t n, u32 nwin_local, u32 nb) {
-    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n * nwin_local) return;
-    const u32 w = (u32)(g / n);
-    const u32 i = (u32)(g - (size_t)w * n);
-    const u32 enc = digits[g];
-    if (!enc) return;
-    const u32 b = (enc & ~SIGN_BIT) - 1;
-    const u32 pos = atomicAdd(&cursor[(size_t)w * nb + b], 1u);
-    sorted[(size_t)w * n + pos] = i | (enc & SIGN_BIT);
 }
 
 // ---- HOT KERNEL: segment accumulation -------------------------------------------------------------------
@@ -234,27 +262,30 @@ __global__ __launch_bounds__(128) void k_accumulate(const u32* __restrict__ poin
     u32 b = lo;
     u32 b_start = off[b], b_end = b_start + cnt[b];
     X acc = Cv::infinity();
-    u32 x = pos0;
-    while (x < pos1) {
-        const u32 run_end = min(b_end, pos1);
-        for (; x < run_end; ++x) {
-            const u32 e = src[x];
-            A p = ld_affine<Cv>(points + (pts_off + (size_t)(e & ~SIGN_BIT)) * Cv::AW);
-            if (e & SIGN_BIT) p = Cv::neg(p);
-            acc = Cv::add_mixed(acc, p);
-        }
-        // flush the run [max(pos0,b_start), run_end) of bucket b
+    // Flat loop: every lane of the wave executes exactly (pos1 - pos0) additions; a run boundary is a short
+    // predicated flush inside the iteration, never a separate inner loop (which would make the wave iterate
+    // max-run-length times per run and double the instruction count).
+    auto flush = [&](u32 end_x) {
         u32* dst;
         if (b_start >= pos0 && b_end <= pos1) dst = bucket_sums + ((size_t)w * nb + b) * Cv::XW;
-        else if (max(pos0, b_start) == pos0) dst = edge_first + ((size_t)w * nseg + k) * Cv::XW;
+        else if (b_start <= pos0) dst = edge_first + ((size_t)w * nseg + k) * Cv::XW;
         else dst = edge_last + ((size_t)w * nseg + k) * Cv::XW;
         st_xyzz<Cv>(acc, dst);
-        acc = Cv::infinity();
-        if (x < pos1) {   // advance to the next non-empty bucket (it starts at x)
+        (void)end_x;
+    };
+    for (u32 x = pos0; x < pos1; ++x) {
+        if (x == b_end) {                       // bucket b is exhausted: store its run, move to the next non-empty bucket
+            flush(x);
+            acc = Cv::infinity();
             do { ++b; } while (cnt[b] == 0);
             b_start = off[b]; b_end = b_start + cnt[b];
         }
+        const u32 e = src[x];
+        A p = ld_affine<Cv>(points + (pts_off + (size_t)(e & ~SIGN_BIT)) * Cv::AW);
+        if (e & SIGN_BIT) p = Cv::neg(p);
+        acc = Cv::add_mixed(acc, p);
     }
+    flush(pos1);
 }
 
 // lane per bucket: empty -> infinity; spanning <= FIX_LIGHT segments -> stitch serially; more -> heavy list
