@@ -71,6 +71,15 @@ def load_library():
         "dvn_ntt": (i32, [vp, vp, vp, C.c_int, C.c_int, C.c_int, u32]),
         "dvn_groth16_compute_h": (i32, [vp, vp, vp, vp, vp, sz, vp, u32]),
         "dvn_last_kernel_ms": (i32, [vp, C.c_int, C.POINTER(C.c_float)]),
+        "dvn_r1cs_synthetic": (i32, [u64, u32, u32, C.POINTER(vp)]),
+        "dvn_r1cs_info": (i32, [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),
+        "dvn_r1cs_witness": (i32, [vp, vp]),
+        "dvn_r1cs_free": (None, [vp]),
+        "dvn_groth16_setup": (i32, [vp, vp, u64, C.POINTER(vp)]),
+        "dvn_groth16_pk_info": (i32, [vp, C.POINTER(u32), C.POINTER(u64)]),
+        "dvn_groth16_pk_free": (i32, [vp, vp]),
+        "dvn_groth16_prove": (i32, [vp, vp, vp, u32, vp, vp, vp]),
+        "dvn_groth16_last_ms": (i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)           # AttributeError here = header/library mismatch
@@ -85,7 +94,8 @@ EXPORTED_SYMBOLS = [
     "dvn_memcpy_d2h", "dvn_synchronize", "dvn_points_upload_g1", "dvn_points_upload_g2", "dvn_points_synthetic_g1",
     "dvn_points_synthetic_g2", "dvn_scalars_synthetic", "dvn_points_download", "dvn_points_len", "dvn_points_free", "dvn_msm_g1", "dvn_msm_g2",
     "dvn_msm_plan", "dvn_msm_g1_windows", "dvn_msm_combine_g1", "dvn_ntt_domain", "dvn_ntt_domain_free", "dvn_ntt",
-    "dvn_groth16_compute_h", "dvn_last_kernel_ms",
+    "dvn_groth16_compute_h", "dvn_last_kernel_ms", "dvn_r1cs_synthetic", "dvn_r1cs_info", "dvn_r1cs_witness", "dvn_r1cs_free",
+    "dvn_groth16_setup", "dvn_groth16_pk_info", "dvn_groth16_pk_free", "dvn_groth16_prove", "dvn_groth16_last_ms",
 ]
 
 
@@ -251,3 +261,63 @@ class Context:
 
     def last_kernel_ms(self, which: int = 0) -> float:
         ms = C.c_float(); self._chk(self.L.dvn_last_kernel_ms(self.h, which, C.byref(ms))); return float(ms.value)
+
+
+class R1CS:
+    """Host-side sparse R1CS handle (dvn_r1cs): the synthetic multiplication-gate instance of SURVEY.md §8d."""
+
+    def __init__(self, seed: int, n_constraints: int, n_public: int):
+        self.L = load_library()
+        h = C.c_void_p()
+        rc = self.L.dvn_r1cs_synthetic(seed, n_constraints, n_public, C.byref(h))
+        if rc != 0:
+            raise DvnError(rc, self.L.dvn_last_error(None).decode())
+        self.h = h
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self.L.dvn_r1cs_info(h, C.byref(a), C.byref(b), C.byref(c))
+        self.n_wires, self.n_public, self.n_constraints = a.value, b.value, c.value
+
+    def witness(self) -> np.ndarray:
+        out = np.zeros((self.n_wires, 4), dtype=np.uint64)
+        self.L.dvn_r1cs_witness(self.h, _host(out))
+        return out
+
+    def free(self):
+        if self.h:
+            self.L.dvn_r1cs_free(self.h)
+            self.h = None
+
+
+class Groth16Key:
+    """Device-resident proving key (dvn_groth16_pk) produced by the Setup mirror."""
+
+    def __init__(self, ctx: Context, cs: R1CS, seed: int):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx._chk(ctx.L.dvn_groth16_setup(ctx.h, cs.h, seed, C.byref(h)))
+        self.h = h
+        ln = C.c_uint32(); sizes = (C.c_uint64 * 5)()
+        ctx.L.dvn_groth16_pk_info(h, C.byref(ln), sizes)
+        self.log_n = ln.value
+        self.sizes = dict(zip(("A", "B", "K", "Z", "B2"), (int(v) for v in sizes)))
+
+    def prove(self, witness, r_mont: np.ndarray, s_mont: np.ndarray) -> dict:
+        """witness: (m,4) uint64 host array or int device pointer.  Returns {'Ar': (8,), 'Bs': (16,), 'Krs': (8,)}."""
+        out = np.zeros(32, dtype=np.uint64)
+        r_mont = np.ascontiguousarray(r_mont, dtype=np.uint64); s_mont = np.ascontiguousarray(s_mont, dtype=np.uint64)
+        if isinstance(witness, (int, np.integer)):
+            wp, fl = C.c_void_p(int(witness)), 1
+        else:
+            witness = np.ascontiguousarray(witness, dtype=np.uint64); wp, fl = _host(witness), 0
+        self.ctx._chk(self.ctx.L.dvn_groth16_prove(self.ctx.h, self.h, wp, fl, _host(r_mont), _host(s_mont), _host(out)))
+        return {"Ar": out[0:8].copy(), "Bs": out[8:24].copy(), "Krs": out[24:32].copy()}
+
+    def last_ms(self):
+        a, b, c = C.c_float(), C.c_float(), C.c_float()
+        self.ctx.L.dvn_groth16_last_ms(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return {"compute_h": a.value, "msm": b.value, "total": c.value}
+
+    def free(self):
+        if self.h:
+            self.ctx._chk(self.ctx.L.dvn_groth16_pk_free(self.ctx.h, self.h))
+            self.h = None

@@ -89,3 +89,8 @@ extern "C" int32_t dvn_scalars_synthetic(dvn_ctx* ctx, uint64_t seed, int kind, 
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return DVN_OK;
 }
+
+int32_t dvn_internal_msm_g1_dev(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, G1::X* out) {
+    if (pts->curve != 1) return fail(DVN_ERR_INVALID_ARG, "point set is not G1");
+    return msm_dev_xyzz<G1>(ctx, pts, off, n, d_scalars, out);
+}

@@ -202,6 +202,18 @@ template <class Cv> static void write_jac(const typename Cv::X& p, uint64_t* out
     O::to_ext(a.x, w); O::to_ext(a.y, w + FW); O::to_ext(O::one(), w + 2 * FW);
 }
 
+// device scalars -> internal xyzz (caller holds the lock)
+template <class Cv>
+static int32_t msm_dev_xyzz(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, typename Cv::X* out) {
+    if (off > pts->n || n > pts->n - off) return fail(DVN_ERR_INVALID_ARG, "len(points) != len(scalars): range [%zu, %zu) outside point set of %zu", off, off + n, pts->n);
+    if (n == 0) { *out = Cv::infinity(); return DVN_OK; }
+    u32 c, nwin; msm_plan(n, &c, &nwin);
+    std::vector<u32> sums((size_t)nwin * Cv::XW);
+    TRY(msm_windows<Cv>(ctx, pts, off, n, (const uint64_t*)d_scalars, DVN_MSM_SCALARS_ON_DEVICE, c, nwin, 0, nwin, sums.data()));
+    *out = horner<Cv>(sums.data(), nwin, c);
+    return DVN_OK;
+}
+
 template <class Cv>
 static int32_t msm_full(dvn_ctx* ctx, const dvn_points* pts, int curve, size_t off, size_t n, const uint64_t* scalars, uint32_t flags, uint64_t* out_jac) {
     TRY(enter(ctx));

@@ -40,7 +40,7 @@ __device__ __forceinline__ void st_fr_weak(const Fr& v, u32* p) {
 }
 
 // out[k] = base^(k) * first, k < count; thread handles `chunk` consecutive entries.  base/first internal form.
-__global__ void k_powers(u32* __restrict__ out, const u32* __restrict__ base_first, size_t count, u32 chunk) {
+static __global__ void k_powers(u32* __restrict__ out, const u32* __restrict__ base_first, size_t count, u32 chunk) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t lo = t * chunk;
     if (lo >= count) return;
@@ -67,7 +67,7 @@ __device__ __forceinline__ Fr ntt_scale_factor(const NttScale& sc, u32 i, u32 lo
 }
 
 // stages [sa, sb) of a 2^log_n transform; dit = 0: ascending s (DIF), dit = 1: descending s (DIT)
-__global__ __launch_bounds__(512) void k_ntt_pass(u32* __restrict__ data, const u32* __restrict__ tw, u32 log_n,
+static __global__ __launch_bounds__(512) void k_ntt_pass(u32* __restrict__ data, const u32* __restrict__ tw, u32 log_n,
                                                   u32 sa, u32 sb, int dit, u32 log_i, NttScale sc) {
     extern __shared__ __align__(16) u32 lds[];
     const u32 K = sb - sa, Lb = log_n - sb, I = 1u << log_i;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(512) void k_ntt_pass(u32* __restrict__ data, const 
 
 // computeH pointwise step: a[i] = (a[i] * b[i] - c[i]) * den   (all words external Montgomery)
 // k1 = internal form of den * 2^5, k2 = internal form of den (see bn254_field.h on the 2^-5 reading)
-__global__ void k_h_pointwise(u32* __restrict__ a, const u32* __restrict__ b, const u32* __restrict__ c,
+static __global__ void k_h_pointwise(u32* __restrict__ a, const u32* __restrict__ b, const u32* __restrict__ c,
                               const u32* __restrict__ k1k2, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

@@ -109,6 +109,31 @@ int32_t dvn_ntt(dvn_ctx* ctx, const dvn_domain* dom, uint64_t* data, int inverse
 int32_t dvn_groth16_compute_h(dvn_ctx* ctx, const dvn_domain* dom, const uint64_t* a, const uint64_t* b,
                               const uint64_t* c, size_t len, uint64_t* h_out, uint32_t flags);
 
+/* ---- Groth16 orchestration: what the Go shim's hipGroth16Prove does, in C++ ------------- */
+/* A sparse R1CS  (A w) o (B w) = (C w)  stands in for gnark's constraint.ConstraintSystem.  dvn_r1cs_synthetic builds
+ * the seeded multiplication-gate instance of SURVEY.md §8d config 5 (rows (w[l1] + k w[l2]) * w[r] = w[o], wire 0 =
+ * constant 1, wires 1..n_public-1 public) together with its satisfying wire assignment.  Host only. */
+typedef struct dvn_r1cs dvn_r1cs;
+typedef struct dvn_groth16_pk dvn_groth16_pk;
+int32_t dvn_r1cs_synthetic(uint64_t seed, uint32_t n_constraints, uint32_t n_public, dvn_r1cs** out);
+int32_t dvn_r1cs_info(const dvn_r1cs* cs, uint32_t* n_wires, uint32_t* n_public, uint32_t* n_constraints);
+int32_t dvn_r1cs_witness(const dvn_r1cs* cs, uint64_t* out /* n_wires x 4, Montgomery */);
+void dvn_r1cs_free(dvn_r1cs* cs);
+/* prover.Setup (/root/reference/prover/setup.go:15-28 -> groth16.Setup): toxic waste (tau, alpha, beta, gamma, delta)
+ * drawn from SplitMix64(seed) so the result is reproducible; Lagrange evaluation, K and bit-reversed Z, fixed-base
+ * batch multiplications on the device, InfinityA/B filtering.  The key's point arrays stay resident in HBM. */
+int32_t dvn_groth16_setup(dvn_ctx* ctx, const dvn_r1cs* cs, uint64_t seed, dvn_groth16_pk** out);
+int32_t dvn_groth16_pk_info(const dvn_groth16_pk* pk, uint32_t* log_n, uint64_t sizes[5] /* |A|,|B|,|K|,|Z|,|B2| */);
+int32_t dvn_groth16_pk_free(dvn_ctx* ctx, dvn_groth16_pk* pk);
+/* groth16.Prove (gnark backend/groth16/bn254/prove.go) on a complete wire assignment: (a,b,c) = (Aw,Bw,Cw), computeH,
+ * wire filtering, 4 G1 MSMs + 1 G2 MSM, blinding with the injected (r, s) (gnark draws them from crypto/rand).
+ * witness: n_wires x 4 uint64 Montgomery (host; device pointer if flags & 1).
+ * proof_out: Ar (8) | Bs (16) | Krs (8) uint64 = groth16_bn254.Proof{Ar, Bs, Krs} affine images. */
+int32_t dvn_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
+                          const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32]);
+/* device time of the last dvn_groth16_prove: computeH part (incl. the matrix-vector "solve"), the five MSMs, total */
+int32_t dvn_groth16_last_ms(const dvn_groth16_pk* pk, float* ms_h, float* ms_msm, float* ms_total);
+
 /* ---- timing of the last call's kernels, measured with HIP events on the library's own stream ---------- */
 /* which: 0 = whole device section of the last MSM/NTT call, 1 = its dominant kernel (MSM: bucket
  * accumulation; NTT: sum of butterfly passes). */

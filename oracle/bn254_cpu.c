@@ -350,3 +350,101 @@ int orc_compute_h(const u64* a_in, const u64* b_in, const u64* c_in, size_t len,
 }
 
 int orc_num_threads(void) { return omp_get_max_threads(); }
+
+/* ------------------------------------------------------------------ synthetic Groth16 checker (row a10) */
+/* Restates oracle/bn254_py.py SyntheticR1CS + groth16_setup's trapdoor + groth16_expected_from_trapdoor:
+ * the proof a correct prover must output for injected (r, s), from O(n) field work and three fixed-base
+ * scalar multiplications -- no MSM, no NTT, so it is independent of everything it checks. */
+typedef struct { u64 s; } smix;
+static inline u64 smix_next(smix* g) {
+    g->s += 0x9E3779B97F4A7C15ULL;
+    u64 z = g->s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+static inline void smix_next_fr_mont(smix* g, fe* out) {
+    fe c; for (int k = 0; k < 4; ++k) c.l[k] = smix_next(g);
+    reduce_mod_r(c.l); fr_to_mont(out, &c);
+}
+static inline void fr_from_u64_mont(fe* r, u64 v) { fe c = {{v, 0, 0, 0}}; fr_to_mont(r, &c); }
+
+int orc_groth16_synthetic_expected(u64 cs_seed, uint32_t n_constraints, uint32_t n_public, u64 setup_seed,
+                                   const u64* r_mont, const u64* s_mont, u64* witness_out, u64* proof_out) {
+    const uint32_t n_free = 4;
+    const size_t m = (size_t)n_public + n_free + n_constraints;
+    fe* w = (fe*)malloc(sizeof(fe) * m);
+    uint32_t* l1 = (uint32_t*)malloc(4 * (size_t)n_constraints); uint32_t* l2 = (uint32_t*)malloc(4 * (size_t)n_constraints);
+    uint32_t* rr = (uint32_t*)malloc(4 * (size_t)n_constraints); uint32_t* kk = (uint32_t*)malloc(4 * (size_t)n_constraints);
+    smix g = {cs_seed};
+    size_t cur = 0;
+    fr_set_one(&w[cur++]);
+    for (uint32_t i = 1; i < n_public; ++i) smix_next_fr_mont(&g, &w[cur++]);
+    for (uint32_t i = 0; i < n_free; ++i) smix_next_fr_mont(&g, &w[cur++]);
+    for (uint32_t j = 0; j < n_constraints; ++j) {
+        l1[j] = (uint32_t)(smix_next(&g) % cur); l2[j] = (uint32_t)(smix_next(&g) % cur);
+        kk[j] = (uint32_t)(smix_next(&g) % 7 + 1); rr[j] = (uint32_t)(smix_next(&g) % cur);
+        fe kf, t; fr_from_u64_mont(&kf, kk[j]);
+        fr_mul(&t, &kf, &w[l2[j]]); fr_add(&t, &t, &w[l1[j]]); fr_mul(&w[cur], &t, &w[rr[j]]);
+        ++cur;
+    }
+    if (witness_out) memcpy(witness_out, w, sizeof(fe) * m);
+    /* trapdoor */
+    smix gs = {setup_seed};
+    fe tw[5], one; fr_set_one(&one);
+    for (int i = 0; i < 5; ++i) { smix_next_fr_mont(&gs, &tw[i]); if (fe_is_zero(&tw[i])) tw[i] = one; }
+    const fe tau = tw[0], alpha = tw[1], beta = tw[2], delta = tw[4];
+    int log_n = 1; while (((size_t)1 << log_n) < n_constraints) ++log_n;
+    const size_t n = (size_t)1 << log_n;
+    fe omega; memcpy(omega.l, FR_ROOT_2_28_MONT, 32);
+    for (int i = log_n; i < 28; ++i) fr_mul(&omega, &omega, &omega);
+    /* L_j(tau), j < n_constraints is all that the rows touch */
+    fe ztau, nn, zn; fr_pow_u64(&ztau, &tau, (u64)n); fr_sub(&ztau, &ztau, &one);
+    fr_from_u64_mont(&nn, (u64)n); fr_inv(&nn, &nn); fr_mul(&zn, &ztau, &nn);
+    fe* wj = (fe*)malloc(sizeof(fe) * n_constraints); fe* den = (fe*)malloc(sizeof(fe) * n_constraints);
+    fe* pre = (fe*)malloc(sizeof(fe) * n_constraints); fe* L = (fe*)malloc(sizeof(fe) * n_constraints);
+    fe curw = one, acc = one;
+    for (uint32_t j = 0; j < n_constraints; ++j) { wj[j] = curw; fr_sub(&den[j], &tau, &curw); pre[j] = acc; fr_mul(&acc, &acc, &den[j]); fr_mul(&curw, &curw, &omega); }
+    fe inv; fr_inv(&inv, &acc);
+    for (uint32_t j = n_constraints; j-- > 0;) {
+        fe di; fr_mul(&di, &inv, &pre[j]); fr_mul(&inv, &inv, &den[j]);
+        fr_mul(&L[j], &zn, &wj[j]); fr_mul(&L[j], &L[j], &di);
+    }
+    fe* At = (fe*)calloc(m, sizeof(fe)); fe* Bt = (fe*)calloc(m, sizeof(fe)); fe* Ct = (fe*)calloc(m, sizeof(fe));
+    for (uint32_t j = 0; j < n_constraints; ++j) {
+        fe kf, t;
+        if (l1[j] != l2[j]) { fr_add(&At[l1[j]], &At[l1[j]], &L[j]); fr_from_u64_mont(&kf, kk[j]); fr_mul(&t, &kf, &L[j]); fr_add(&At[l2[j]], &At[l2[j]], &t); }
+        else { fr_from_u64_mont(&kf, 1 + (u64)kk[j]); fr_mul(&t, &kf, &L[j]); fr_add(&At[l1[j]], &At[l1[j]], &t); }
+        fr_add(&Bt[rr[j]], &Bt[rr[j]], &L[j]);
+        size_t o = (size_t)n_public + n_free + j;
+        fr_add(&Ct[o], &Ct[o], &L[j]);
+    }
+    fe a_tau = {{0}}, b_tau = {{0}}, c_tau = {{0}}, priv = {{0}}, dinv, t;
+    fr_inv(&dinv, &delta);
+    for (size_t i = 0; i < m; ++i) {
+        fr_mul(&t, &w[i], &At[i]); fr_add(&a_tau, &a_tau, &t);
+        fr_mul(&t, &w[i], &Bt[i]); fr_add(&b_tau, &b_tau, &t);
+        fr_mul(&t, &w[i], &Ct[i]); fr_add(&c_tau, &c_tau, &t);
+        if (i >= n_public) {
+            fe k1, k2; fr_mul(&k1, &beta, &At[i]); fr_mul(&k2, &alpha, &Bt[i]); fr_add(&k1, &k1, &k2); fr_add(&k1, &k1, &Ct[i]);
+            fr_mul(&k1, &k1, &dinv); fr_mul(&k1, &k1, &w[i]); fr_add(&priv, &priv, &k1);
+        }
+    }
+    fe r, s, ar, bs, krs, h_tau, zi;
+    memcpy(r.l, r_mont, 32); memcpy(s.l, s_mont, 32);
+    fr_inv(&zi, &ztau);
+    fr_mul(&h_tau, &a_tau, &b_tau); fr_sub(&h_tau, &h_tau, &c_tau); fr_mul(&h_tau, &h_tau, &zi);
+    fr_mul(&t, &r, &delta); fr_add(&ar, &alpha, &a_tau); fr_add(&ar, &ar, &t);
+    fr_mul(&t, &s, &delta); fr_add(&bs, &beta, &b_tau); fr_add(&bs, &bs, &t);
+    fr_mul(&krs, &h_tau, &ztau); fr_mul(&krs, &krs, &dinv); fr_add(&krs, &krs, &priv);
+    fr_mul(&t, &s, &ar); fr_add(&krs, &krs, &t);
+    fr_mul(&t, &r, &bs); fr_add(&krs, &krs, &t);
+    fr_mul(&t, &r, &s); fr_mul(&t, &t, &delta); fr_sub(&krs, &krs, &t);
+    fe arc, bsc, krsc; fr_from_mont(&arc, &ar); fr_from_mont(&bsc, &bs); fr_from_mont(&krsc, &krs);
+    u64 gen1[8]; orc_g1_generator(gen1);
+    orc_g1_mul(gen1, arc.l, proof_out);
+    orc_g2_mul(G2_GEN_MONT, bsc.l, proof_out + 8);
+    orc_g1_mul(gen1, krsc.l, proof_out + 24);
+    free(w); free(l1); free(l2); free(rr); free(kk); free(wj); free(den); free(pre); free(L); free(At); free(Bt); free(Ct);
+    return (int)m;
+}

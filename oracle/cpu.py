@@ -156,3 +156,13 @@ def compute_h(a, b, c, log_n: int, nthreads: int = 0) -> np.ndarray:
 
 def num_threads() -> int:
     return int(lib().orc_num_threads())
+
+
+def groth16_synthetic_expected(cs_seed: int, n_constraints: int, n_public: int, setup_seed: int, r_mont, s_mont):
+    """Closed-form proof from the trapdoor for the synthetic instance.  Returns (witness (m,4), {'Ar','Bs','Krs'})."""
+    m = n_public + 4 + n_constraints
+    wit = u64((m, 4)); proof = u64(32)
+    r_mont = np.ascontiguousarray(r_mont, dtype=np.uint64); s_mont = np.ascontiguousarray(s_mont, dtype=np.uint64)
+    lib().orc_groth16_synthetic_expected(C.c_uint64(cs_seed), C.c_uint32(n_constraints), C.c_uint32(n_public), C.c_uint64(setup_seed),
+                                         _p(r_mont), _p(s_mont), _p(wit), _p(proof))
+    return wit, {"Ar": proof[0:8].copy(), "Bs": proof[8:24].copy(), "Krs": proof[24:32].copy()}

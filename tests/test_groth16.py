@@ -1,0 +1,75 @@
+"""Groth16 orchestration: the library's Setup + Prove on the synthetic statetransition-shaped
+instance against the trapdoor identity -- the proof must equal [alpha + sum w_i A_i(tau) + r delta]G1 etc. bit for bit
+for the injected (r, s).  The checker (oracle) uses no MSM and no NTT."""
+import numpy as np
+import pytest
+
+R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+
+
+def mont(o, x):
+    return np.array(o.limbs(o.to_mont(x % R, R)), dtype=np.uint64)
+
+
+def test_synthetic_r1cs_witness_matches_oracle(pkg, opy, orc):
+    """Host-only part of the library (no GPU needed): the seeded instance and its satisfying assignment."""
+    cs = pkg.R1CS(11, 13, 3)
+    assert (cs.n_wires, cs.n_public, cs.n_constraints) == (3 + 4 + 13, 3, 13)
+    ref = opy.SyntheticR1CS(13, 3, 11)
+    assert [opy.from_mont(opy.from_limbs(r), R) for r in cs.witness()] == ref.witness
+    cs.free()
+    cs = pkg.R1CS(5, 3000, 9)
+    wit, _ = orc.groth16_synthetic_expected(5, 3000, 9, 3, mont(opy, 1), mont(opy, 2))
+    assert (cs.witness() == wit).all()
+    cs.free()
+
+
+@pytest.mark.gpu
+def test_groth16_small_instance_vs_python_oracle(ctx, pkg, opy):
+    o = opy
+    cs = pkg.R1CS(11, 13, 3)
+    key = pkg.Groth16Key(ctx, cs, 3)
+    ref = o.SyntheticR1CS(13, 3, 11)
+    pk, trap = o.groth16_setup(ref, 3)
+    r, s = 1234567, 7654321
+    want = o.groth16_prove(ref, pk, r, s)                       # MSM/NTT-based python prover
+    closed = o.groth16_expected_from_trapdoor(ref, trap, pk["domain"], r, s)
+    assert want["Ar"] == closed["Ar"] and want["Bs"] == closed["Bs"] and want["Krs"] == closed["Krs"]
+    got = key.prove(cs.witness(), mont(o, r), mont(o, s))
+    assert list(got["Ar"]) == o.g1_to_limbs(want["Ar"])
+    assert list(got["Bs"]) == o.g2_to_limbs(want["Bs"])
+    assert list(got["Krs"]) == o.g1_to_limbs(want["Krs"])
+    # key shape: gnark drops points at infinity from A and B (InfinityA/B)
+    nzA = sum(1 for v in trap["At"] if v); nzB = sum(1 for v in trap["Bt"] if v)
+    assert key.sizes == {"A": nzA, "B": nzB, "K": ref.n_wires - 3, "Z": 16, "B2": nzB}
+    key.free(); cs.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_constraints,n_public", [(100, 1), (1 << 12, 9), ((1 << 14) - 5, 9), (1 << 16, 9)])
+def test_groth16_trapdoor_identity(ctx, pkg, opy, orc, n_constraints, n_public):
+    cs = pkg.R1CS(7, n_constraints, n_public)
+    key = pkg.Groth16Key(ctx, cs, 3)
+    for r, s in ((1234567, 7654321), (0, 0), (R - 1, 5)):
+        wit, want = orc.groth16_synthetic_expected(7, n_constraints, n_public, 3, mont(opy, r), mont(opy, s))
+        got = key.prove(cs.witness(), mont(opy, r), mont(opy, s))
+        for k in ("Ar", "Bs", "Krs"):
+            assert (got[k] == want[k]).all(), (k, r, s)
+    # device-resident witness (HBM hand-off) gives the same proof
+    d = ctx.to_device(cs.witness())
+    got2 = key.prove(d, mont(opy, 1234567), mont(opy, 7654321))
+    _, want = orc.groth16_synthetic_expected(7, n_constraints, n_public, 3, mont(opy, 1234567), mont(opy, 7654321))
+    assert all((got2[k] == want[k]).all() for k in want)
+    ctx.free(d); key.free(); cs.free()
+
+
+@pytest.mark.gpu
+def test_groth16_wrong_witness_changes_proof(ctx, pkg, opy, orc):
+    """Sanity of the checker itself: a corrupted assignment must not reproduce the trapdoor proof."""
+    cs = pkg.R1CS(7, 500, 9)
+    key = pkg.Groth16Key(ctx, cs, 3)
+    w = cs.witness(); w[100] = w[101]
+    got = key.prove(w, mont(opy, 1), mont(opy, 2))
+    _, want = orc.groth16_synthetic_expected(7, 500, 9, 3, mont(opy, 1), mont(opy, 2))
+    assert not (got["Krs"] == want["Krs"]).all()
+    key.free(); cs.free()
