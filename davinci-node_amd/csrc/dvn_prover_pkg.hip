@@ -1,0 +1,106 @@
+// C++ mirror of the reference's `prover` package: the seam the sequencer calls.
+//
+//   reference (Go)                                   here
+//   prover/config.go:16-26   UseGPUProver + init()   prover::UseGPUProver, prover::init_from_env()  (GPU_PROVER in {true,y,1,yes})
+//   prover/config.go:29-56   ProverFunc, SetProver   prover::ProverFunc, prover::SetProver
+//   prover/prover_gpu.go:66  Prove                   prover::Prove            -> prover(...)
+//   prover/prover_gpu.go:71  defaultProver           prover::defaultProver    GPU, on ANY error print + CPU fallback
+//   prover/prover_gpu.go:87  CPUProver(+WithWitness) prover::CPUProver        -> the registered CPU backend (gnark in production)
+//   prover/prover_gpu.go:99  GPUProver(+WithWitness) prover::GPUProver        -> callGPUProver: per-curve dispatch, BN254 only
+//   prover/prover_gpu.go:24  callGPUProver           prover::callGPUProver    other curves: "GPU proving not supported for curve"
+//   prover/setup.go:15       Setup                   prover::Setup            -> dvn_groth16_setup, timing log
+// The CPU prover is NOT part of this library: in the node it is gnark's groth16.Prove.  CPUProver therefore calls a
+// backend registered by the embedder (dvn_prover_set_cpu_backend); with none registered it returns an error -- it never
+// silently computes on the CPU.
+#include <chrono>
+#include "dvn_internal.h"
+
+namespace prover {
+
+enum CurveID { UNKNOWN = 0, BN254 = 1, BLS12_377 = 2, BLS12_381 = 3, BW6_761 = 4 };
+static const char* curve_name(int c) {
+    switch (c) { case BN254: return "bn254"; case BLS12_377: return "bls12_377"; case BLS12_381: return "bls12_381"; case BW6_761: return "bw6_761"; default: return "unknown"; }
+}
+
+// request = (curve, ccs, pk, complete wire assignment, blinding factors r and s that gnark draws inside Prove)
+typedef dvn_prover_request Request;
+typedef dvn_prover_func ProverFunc;
+typedef dvn_cpu_backend CpuBackend;
+
+bool UseGPUProver = false;
+static ProverFunc custom_prover = nullptr; static void* custom_user = nullptr;
+static CpuBackend cpu_backend = nullptr; static void* cpu_user = nullptr;
+static thread_local int last_backend = 0;   // 1 = GPU, 2 = CPU, 3 = custom
+
+void init_from_env() {
+    const char* v = getenv("GPU_PROVER");
+    UseGPUProver = v && (!strcmp(v, "true") || !strcmp(v, "y") || !strcmp(v, "1") || !strcmp(v, "yes"));
+    fprintf(stderr, "[prover] GPU prover usage enabled=%s\n", UseGPUProver ? "true" : "false");
+}
+struct EnvInit { EnvInit() { const char* v = getenv("GPU_PROVER"); UseGPUProver = v && (!strcmp(v, "true") || !strcmp(v, "y") || !strcmp(v, "1") || !strcmp(v, "yes")); } };
+static EnvInit env_init;                     // Go's package init()
+
+int32_t CPUProverWithWitness(const Request* q) {
+    last_backend = 2;
+    if (!cpu_backend) return fail(DVN_ERR_UNSUPPORTED, "CPU prover not linked: register gnark's groth16.Prove with dvn_prover_set_cpu_backend");
+    return cpu_backend(q->curve, q->witness, q->r, q->s, q->proof, cpu_user);
+}
+int32_t callGPUProver(const Request* q) {
+    switch (q->curve) {
+        case BN254:
+            if (!q->pk) return fail(DVN_ERR_INVALID_ARG, "proving key type mismatch for BN254: expected a device-resident dvn_groth16_pk, got NULL");
+            return dvn_groth16_prove(q->ctx, q->pk, q->witness, 0, q->r, q->s, q->proof);
+        default:
+            return fail(DVN_ERR_UNSUPPORTED, "GPU proving not supported for curve %s", curve_name(q->curve));
+    }
+}
+int32_t GPUProverWithWitness(const Request* q) { last_backend = 1; return callGPUProver(q); }
+// frontend.NewWitness(assignment, field) has no counterpart here: the assignment already is the wire vector
+int32_t CPUProver(const Request* q) { return CPUProverWithWitness(q); }
+int32_t GPUProver(const Request* q) { return GPUProverWithWitness(q); }
+
+int32_t ProveWithWitness(const Request* q) {
+    if (UseGPUProver) {
+        int32_t rc = GPUProverWithWitness(q);
+        if (rc != DVN_OK) {
+            printf("GPU proving failed (%s), falling back to CPU\n", tl_error.c_str());
+            fflush(stdout);
+            return CPUProverWithWitness(q);
+        }
+        return rc;
+    }
+    return CPUProverWithWitness(q);
+}
+int32_t defaultProver(const Request* q) { return ProveWithWitness(q); }
+int32_t Prove(const Request* q) {
+    if (custom_prover) { last_backend = 3; return custom_prover(q, custom_user); }
+    return defaultProver(q);
+}
+void SetProver(ProverFunc p, void* user) { custom_prover = p; custom_user = user; }
+
+int32_t Setup(dvn_ctx* ctx, const dvn_r1cs* ccs, uint64_t seed, dvn_groth16_pk** pk) {
+    uint32_t nc = 0; dvn_r1cs_info(ccs, nullptr, nullptr, &nc);
+    fprintf(stderr, "[prover] generating circuit keys gpu=%s constraints=%u\n", UseGPUProver ? "true" : "false", nc);
+    auto t0 = std::chrono::steady_clock::now();
+    int32_t rc = dvn_groth16_setup(ctx, ccs, seed, pk);
+    if (rc == DVN_OK) {
+        double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        fprintf(stderr, "[prover] circuit keys setup done took=%.3fs gpu=%s constraints=%u\n", s, UseGPUProver ? "true" : "false", nc);
+    }
+    return rc;
+}
+}  // namespace prover
+
+// ---- C-ABI of the package mirror -----------------------------------------------------------------------------
+extern "C" int32_t dvn_prover_use_gpu(void) { return prover::UseGPUProver ? 1 : 0; }
+extern "C" void dvn_prover_set_use_gpu(int32_t on) { prover::UseGPUProver = on != 0; }
+extern "C" void dvn_prover_reload_env(void) { prover::init_from_env(); }
+extern "C" void dvn_prover_set_prover(prover::ProverFunc p, void* user) { prover::SetProver(p, user); }
+extern "C" void dvn_prover_set_cpu_backend(prover::CpuBackend b, void* user) { prover::cpu_backend = b; prover::cpu_user = user; }
+extern "C" int32_t dvn_prover_last_backend(void) { return prover::last_backend; }
+extern "C" int32_t dvn_prover_prove(dvn_ctx* ctx, int32_t curve, const dvn_r1cs* ccs, dvn_groth16_pk* pk, const uint64_t* witness,
+                                    const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32]) {
+    prover::Request q{curve, ctx, ccs, pk, witness, r_mont, s_mont, proof_out};
+    return prover::Prove(&q);
+}
+extern "C" int32_t dvn_prover_setup(dvn_ctx* ctx, const dvn_r1cs* ccs, uint64_t seed, dvn_groth16_pk** pk) { return prover::Setup(ctx, ccs, seed, pk); }

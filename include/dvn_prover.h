@@ -134,6 +134,29 @@ int32_t dvn_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witn
 /* device time of the last dvn_groth16_prove: computeH part (incl. the matrix-vector "solve"), the five MSMs, total */
 int32_t dvn_groth16_last_ms(const dvn_groth16_pk* pk, float* ms_h, float* ms_msm, float* ms_total);
 
+/* ---- mirror of the reference's `prover` package (csrc/dvn_prover_pkg.hip) --------------------- */
+/* Same control flow as /root/reference/prover/prover_gpu.go:66-123: Prove -> prover func (SetProver seam) ->
+ * defaultProver: if UseGPUProver (env GPU_PROVER in {true,y,1,yes}, prover/config.go:18-26) try the GPU and on ANY
+ * error print "GPU proving failed (<err>), falling back to CPU" and run the CPU prover.  The CPU prover is the
+ * embedder's (gnark groth16.Prove): register it with dvn_prover_set_cpu_backend; none registered -> error, never a
+ * silent CPU computation.  curve ids: 1 BN254, 2 BLS12-377, 3 BLS12-381, 4 BW6-761 (only BN254 has a GPU path,
+ * others return "GPU proving not supported for curve ..." like prover_gpu.go:58-60). */
+typedef struct dvn_prover_request {
+    int curve; dvn_ctx* ctx; const dvn_r1cs* ccs; dvn_groth16_pk* pk;
+    const uint64_t* witness; const uint64_t* r; const uint64_t* s; uint64_t* proof;
+} dvn_prover_request;
+typedef int32_t (*dvn_prover_func)(const dvn_prover_request*, void* user);
+typedef int32_t (*dvn_cpu_backend)(int curve, const uint64_t* witness, const uint64_t* r, const uint64_t* s, uint64_t* proof, void* user);
+int32_t dvn_prover_use_gpu(void);
+void dvn_prover_set_use_gpu(int32_t on);
+void dvn_prover_reload_env(void);                                   /* re-run the package init(): read GPU_PROVER */
+void dvn_prover_set_prover(dvn_prover_func p, void* user);          /* prover.SetProver; NULL restores defaultProver */
+void dvn_prover_set_cpu_backend(dvn_cpu_backend b, void* user);
+int32_t dvn_prover_last_backend(void);                              /* 1 GPU, 2 CPU backend, 3 custom prover func */
+int32_t dvn_prover_prove(dvn_ctx* ctx, int32_t curve, const dvn_r1cs* ccs, dvn_groth16_pk* pk, const uint64_t* witness,
+                         const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32]);
+int32_t dvn_prover_setup(dvn_ctx* ctx, const dvn_r1cs* ccs, uint64_t seed, dvn_groth16_pk** pk);   /* prover.Setup */
+
 /* ---- timing of the last call's kernels, measured with HIP events on the library's own stream ---------- */
 /* which: 0 = whole device section of the last MSM/NTT call, 1 = its dominant kernel (MSM: bucket
  * accumulation; NTT: sum of butterfly passes). */
