@@ -303,8 +303,15 @@ template <> struct Ops<Fp> {
 #pragma unroll
         for (int i = 0; i < 8; ++i) w[i] = t[i]; }
 };
+// Fp multiplication as a real call: Fp2 code stays compact (an inlined G2 kernel exceeds 10^5 instructions)
+static DVN_NOINLINE Fp fp_mul_call(Fp a, Fp b) { return fe_mul<FpCfg>(a, b); }
+static DVN_NOINLINE Fp fp_sqr_call(Fp a) { return fe_sqr<FpCfg>(a); }
+struct OpsFpCall : Ops<Fp> {
+    static DVN_HD Fp mul(const Fp& a, const Fp& b) { return fp_mul_call(a, b); }
+    static DVN_HD Fp sqr(const Fp& a) { return fp_sqr_call(a); }
+};
 template <> struct Ops<Fp2> {
-    typedef Ops<Fp> B;
+    typedef OpsFpCall B;
     static DVN_HD Fp2 zero() { return Fp2{B::zero(), B::zero()}; }
     static DVN_HD Fp2 one() { return Fp2{B::one(), B::zero()}; }
     static DVN_HD Fp2 add(const Fp2& a, const Fp2& b) { return Fp2{B::add(a.a0, b.a0), B::add(a.a1, b.a1)}; }
@@ -327,7 +334,7 @@ template <> struct Ops<Fp2> {
     static DVN_HD bool is_zero(const Fp2& a) { return B::is_zero(a.a0) && B::is_zero(a.a1); }
     static DVN_HD bool is_literal_zero(const Fp2& a) { return B::is_literal_zero(a.a0) && B::is_literal_zero(a.a1); }
     static constexpr int WORDS = 16;
-    static constexpr bool OUTLINE = true;
+    static constexpr bool OUTLINE = false;
     static DVN_HD Fp2 load_internal(const u32* w) { return Fp2{B::load_internal(w), B::load_internal(w + 8)}; }
     static DVN_HD void store_internal(const Fp2& a, u32* w) { B::store_internal(a.a0, w); B::store_internal(a.a1, w + 8); }
     static DVN_HD Fp2 from_ext(const u32* w) { return Fp2{B::from_ext(w), B::from_ext(w + 8)}; }

@@ -96,7 +96,7 @@ static int32_t msm_windows(dvn_ctx* ctx, const dvn_points* pts, size_t off, size
     u32 seg = 16;
     while (seg < 128 && (double)n * W / seg > 262144.0) seg <<= 1;
     const u32 nseg = (u32)((n + seg - 1) / seg);
-    const u32 L = 32;                                              // buckets per thread in the reduction
+    const u32 L = 8;                                               // buckets per thread in the reduction (latency-bound: keep chains short)
     const u32 bpw = (nb + 256 * L - 1) / (256 * L);                // reduction blocks per window
     const u32 heavy_cap = (u32)(((size_t)W * nseg) / (FIX_LIGHT - 1) + 1);
     const bool on_dev = flags & DVN_MSM_SCALARS_ON_DEVICE;
