@@ -55,11 +55,20 @@ def main():
     import __graft_entry__ as g
     pkg = g.load_package()                      # raises if libdvn_prover.so is missing: no fallback
     dist = None
+    # DVN_BENCH_BACKEND=gloo: debugging aid for 1-GPU boxes -- all ranks share device 0 and exchange through host
+    # memory (RCCL refuses two ranks on one device).  The driver's multi-GPU run uses the default, nccl (= RCCL).
+    backend = os.environ.get("DVN_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    xdev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    ctx = pkg.Context(local_rank)
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    ctx = pkg.Context(dev_index)
 
     n = 1 << args.log_n
     c, nwin = ctx.msm_plan(n)
@@ -78,7 +87,7 @@ def main():
         if world == 1:
             out = ctx.msm_g1(pts, scal_dev, n=n)
         else:
-            out = sharding.sharded_msm_g1(ctx, pts, scal_dev, n, rank, world, dist, "cuda")
+            out = sharding.sharded_msm_g1(ctx, pts, scal_dev, n, rank, world, dist, xdev)
         acc_ms.append(ctx.last_kernel_ms(1)); dev_ms.append(ctx.last_kernel_ms(0))
         return out
 
@@ -99,7 +108,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -128,6 +137,7 @@ def main():
         m = 1 << min(args.cpu_sample_log_n, args.log_n)
         ph = pts.download(0, m)
         sh = np.ascontiguousarray(sm[:m])
+        orc.msm_g1(ph[:1 << 14], sh[:1 << 14])            # warm the OpenMP pool / page in the library
         t0 = time.perf_counter()
         want = orc.msm_g1(ph, sh)
         dt = time.perf_counter() - t0

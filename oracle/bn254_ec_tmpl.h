@@ -160,13 +160,22 @@ static void ECN(msm_ex)(ECN(xyzz)* result, const ECN(aff)* points, const u64* sc
             digits[(size_t)w * n + i] = (int32_t)d;
         }
     }
+    /* one task per (window, point chunk) so that more threads than windows are used -- gnark likewise splits
+     * heavy chunks; every task owns its buckets and reduces them, the per-window sums of the chunks are added */
     ECN(xyzz)* wsum = (ECN(xyzz)*)malloc(sizeof(ECN(xyzz)) * nwin);
+    int nchunk = (nthreads + nwin - 1) / nwin;
+    if (nchunk < 1) nchunk = 1;
+    while (nchunk > 1 && n / (size_t)nchunk < 4 * nb) --nchunk;      /* keep chunks much larger than the bucket count */
+    const int ntask = nwin * nchunk;
+    ECN(xyzz)* tsum = (ECN(xyzz)*)malloc(sizeof(ECN(xyzz)) * ntask);
     #pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
-    for (int w = 0; w < nwin; ++w) {
+    for (int task = 0; task < ntask; ++task) {
+        const int w = task / nchunk, ch = task % nchunk;
+        const size_t lo = n * (size_t)ch / nchunk, hi = n * (size_t)(ch + 1) / nchunk;
         ECN(xyzz)* buckets = (ECN(xyzz)*)malloc(sizeof(ECN(xyzz)) * nb);
         for (size_t b = 0; b < nb; ++b) ECN(xyzz_set_inf)(&buckets[b]);
         const int32_t* dg = digits + (size_t)w * n;
-        for (size_t i = 0; i < n; ++i) {
+        for (size_t i = lo; i < hi; ++i) {
             int32_t d = dg[i];
             if (d == 0) continue;
             if (d > 0) ECN(xyzz_add_aff)(&buckets[d - 1], &points[i], 0);
@@ -177,9 +186,14 @@ static void ECN(msm_ex)(ECN(xyzz)* result, const ECN(aff)* points, const u64* sc
             ECN(xyzz_add)(&run, &buckets[b]);
             ECN(xyzz_add)(&tot, &run);
         }
-        wsum[w] = tot;
+        tsum[task] = tot;
         free(buckets);
     }
+    for (int w = 0; w < nwin; ++w) {
+        wsum[w] = tsum[w * nchunk];
+        for (int ch = 1; ch < nchunk; ++ch) ECN(xyzz_add)(&wsum[w], &tsum[w * nchunk + ch]);
+    }
+    free(tsum);
     ECN(xyzz) acc; ECN(xyzz_set_inf)(&acc);
     for (int w = nwin - 1; w >= 0; --w) {
         for (int k = 0; k < c; ++k) ECN(xyzz_dbl)(&acc);
