@@ -72,6 +72,39 @@ template <class F> struct Curve {
         F Y3 = O::sub(O::mul(R, O::sub(Q, X3)), O::mul(S1, PPP));
         return X{X3, Y3, O::mul(O::mul(p.zz, q.zz), PP), O::mul(O::mul(p.zzz, q.zzz), PPP)};
     }
+    // Accumulator form for the MSM hot loop (G1): coordinates are LOOSE -- x < 8p, y < 2p, zz, zzz < 2p, limbs
+    // normalised -- so the additive steps are single carry passes and Y3 shares one Montgomery reduction between its
+    // two products.  Bounds (units of p): P = U2 + 8p - X1 < 9.1, R = S2 + 2p - Y1 < 3.1, PP < 1.5, PPP, Q, RR < 1.1,
+    // X3 = RR + 2p - PPP + 4p - 2Q < 7.1, QX = Q + 8p - X3 < 9.1, Y3 = (R QX + (2p - Y1) PPP)/R' < 1.2.
+    static DVN_HD X acc_add_mixed(const X& p, const A& q) {
+        if constexpr (!O::LAZY) {
+            return add_mixed(p, q);
+        } else {
+            typedef typename O::Cfg C;
+            if (is_inf(q)) return p;
+            if (is_inf(p)) return X{q.x, q.y, O::one(), O::one()};
+            const F U2 = O::mul(q.x, p.zz), S2 = O::mul(q.y, p.zzz);
+            const F P = fe_sub_lazy<C, 8>(U2, p.x), R = fe_sub_lazy<C, 2>(S2, p.y);
+            if (fe_is_zero_loose<C>(P)) {
+                if (fe_is_zero_loose<C>(R)) return dbl_affine(q);
+                return infinity();
+            }
+            const F PP = O::sqr(P), PPP = O::mul(P, PP), Q = O::mul(p.x, PP);
+            const F X3 = fe_sub_lazy<C, 4>(fe_sub_lazy<C, 2>(O::sqr(R), PPP), fe_add_nocarry<C>(Q, Q));
+            const F Y3 = fe_mul_add<C>(R, fe_sub_lazy<C, 8>(Q, X3), fe_neg_lazy<C, 2>(p.y), PPP);
+            return X{X3, Y3, O::mul(p.zz, PP), O::mul(p.zzz, PPP)};
+        }
+    }
+    // loose accumulator -> weak form (before it is stored or handed to the regular group law)
+    static DVN_HD X acc_normalize(const X& p) {
+        if constexpr (!O::LAZY) return p;
+        else {
+            if (is_inf(p)) return p;
+            typedef typename O::Cfg C;
+            return X{fe_reduce_loose<C>(p.x), p.y, p.zz, p.zzz};
+        }
+    }
+
     // Group operations.  For G2 (Fp2: ~3x the code of G1 per operation) they are real calls: fully inlined,
     // the G2 kernels exceed 10^5 instructions and need long-branch relaxation; outlined they stay small.
     static DVN_NOINLINE X dbl_out(const X& p) { return dbl_impl(p); }

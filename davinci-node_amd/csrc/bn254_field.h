@@ -52,7 +52,10 @@ struct FpCfg {   // base field, p: /root/reference/config/statetransition_vkey.s
     DVN_TABLE(r2, 0x059bac10u, 0x0d1503a3u, 0x018016b8u, 0x10ab0ca8u, 0x02632639u, 0x02c0169fu, 0x169bfd53u, 0x11869d4cu, 0x002a11a6u)
     DVN_TABLE(conv_in, 0x13349ca1u, 0x1a5d84a8u, 0x0a3e5cacu, 0x100249e0u, 0x12b951e8u, 0x0e92d304u, 0x14cb95b3u, 0x041b9d3du, 0x00058003u)
     DVN_TABLE(conv_out, 0x058f0d9du, 0x1aea1c6eu, 0x11c2cf74u, 0x11d651ebu, 0x1462c0a7u, 0x11b7bc3cu, 0x1cbd99bau, 0x183340fbu, 0x000e0a77u)
+    DVN_TABLE(p4, 0x01f3f51cu, 0x041182dbu, 0x11ca8d3cu, 0x0b548b43u, 0x161765e0u, 0x0b6d0302u, 0x029b8504u, 0x197098d0u, 0x00c19139u)
+    DVN_TABLE(p8, 0x03e7ea38u, 0x082305b6u, 0x03951a78u, 0x16a91687u, 0x0c2ecbc0u, 0x16da0605u, 0x05370a08u, 0x12e131a0u, 0x01832273u)
     static constexpr u32 inv = 0x04866389u;   // -p^-1 mod 2^29
+    static constexpr u32 pinv = 0x1b799c77u;  //  p^-1 mod 2^29
 };
 struct FrCfg {   // scalar field, r: /root/reference/config/statetransition_vkey.sol:43
     DVN_TABLE(p, 0x10000001u, 0x1f0fac9fu, 0x0e5c2450u, 0x07d090f3u, 0x1585d283u, 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu)
@@ -61,7 +64,10 @@ struct FrCfg {   // scalar field, r: /root/reference/config/statetransition_vkey
     DVN_TABLE(r2, 0x05b69bd4u, 0x06170a5au, 0x020cddceu, 0x1db6310bu, 0x0e54d0ffu, 0x1cf855e3u, 0x1c15e103u, 0x07d09161u, 0x000a054au)
     DVN_TABLE(conv_in, 0x0fffead7u, 0x1d5444f4u, 0x04438aa5u, 0x03b4d096u, 0x134c84dau, 0x0e92d304u, 0x14cb95b3u, 0x041b9d3du, 0x00058003u)
     DVN_TABLE(conv_out, 0x0ffffffbu, 0x04b1a0e2u, 0x18334a6bu, 0x18ed2b3eu, 0x1462e36fu, 0x11b7bc3cu, 0x1cbd99bau, 0x183340fbu, 0x000e0a77u)
+    DVN_TABLE(p4, 0x00000004u, 0x1c3eb27eu, 0x19709143u, 0x1f4243cdu, 0x16174a0cu, 0x0b6d0302u, 0x029b8504u, 0x197098d0u, 0x00c19139u)
+    DVN_TABLE(p8, 0x00000008u, 0x187d64fcu, 0x12e12287u, 0x1e84879bu, 0x0c2e9419u, 0x16da0605u, 0x05370a08u, 0x12e131a0u, 0x01832273u)
     static constexpr u32 inv = 0x0fffffffu;   // -r^-1 mod 2^29
+    static constexpr u32 pinv = 0x10000001u;  //  r^-1 mod 2^29
 };
 
 template <class C>
@@ -165,6 +171,74 @@ template <class C> DVN_HD Fe<C> fe_sqr(const Fe<C>& a) {
     for (int k = NL; k < 2 * NL - 1; ++k) { T[k + 1] += T[k] >> LB; r.v[k - NL] = (u32)T[k] & LMASK; }
     r.v[NL - 1] = (u32)T[2 * NL - 1];
     return r;
+}
+
+template <class C> DVN_HD bool fe_is_zero(const Fe<C>& a);
+
+// ---- lazily reduced forms (hot loop of k_accumulate) --------------------------------------------------------
+// "Loose" elements have normalised limbs (limbs 0..7 < 2^29) but a value anywhere below 13p; fe_mul / fe_sqr accept them
+// (output < p (1 + A B / 169) for inputs < A p, B p because 2^261 / p > 169) so most additive steps need one carry
+// pass and no conditional correction.
+template <class C, int K> DVN_HD constexpr u32 fe_kp(int i) { return K == 2 ? C::p2(i) : K == 4 ? C::p4(i) : C::p8(i); }
+// a + K p - b  (K in {2, 4, 8}; requires b < K p): value < a + K p, limbs normalised
+template <class C, int K> DVN_HD Fe<C> fe_sub_lazy(const Fe<C>& a, const Fe<C>& b) {
+    i32 d[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) d[i] = (i32)a.v[i] + (i32)fe_kp<C, K>(i) - (i32)b.v[i];
+    fe_carry<C>(d);
+    Fe<C> r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.v[i] = (u32)d[i];
+    return r;
+}
+// K p - b
+template <class C, int K> DVN_HD Fe<C> fe_neg_lazy(const Fe<C>& b) {
+    i32 d[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) d[i] = (i32)fe_kp<C, K>(i) - (i32)b.v[i];
+    fe_carry<C>(d);
+    Fe<C> r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.v[i] = (u32)d[i];
+    return r;
+}
+// a + b without carry propagation: limbs < 2^30; only valid as the subtrahend of fe_sub_lazy or a fe_mul operand
+template <class C> DVN_HD Fe<C> fe_add_nocarry(const Fe<C>& a, const Fe<C>& b) {
+    Fe<C> r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.v[i] = a.v[i] + b.v[i];
+    return r;
+}
+// (a*b + c*d) / 2^261 mod p with ONE Montgomery reduction.  Limbs of all four < 2^29 (top limb free), values loose.
+template <class C> DVN_HD Fe<C> fe_mul_add(const Fe<C>& a, const Fe<C>& b, const Fe<C>& c, const Fe<C>& d) {
+    u64 T[2 * NL];
+#pragma unroll
+    for (int k = 0; k < 2 * NL; ++k) T[k] = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+#pragma unroll
+        for (int j = 0; j < NL; ++j) { T[i + j] += (u64)a.v[i] * b.v[j]; T[i + j] += (u64)c.v[i] * d.v[j]; }
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        const u32 m = ((u32)T[k] * C::inv) & LMASK;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) T[k + j] += (u64)m * C::p(j);
+        T[k + 1] += T[k] >> LB;
+    }
+    Fe<C> r;
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; ++k) { T[k + 1] += T[k] >> LB; r.v[k - NL] = (u32)T[k] & LMASK; }
+    r.v[NL - 1] = (u32)T[2 * NL - 1];
+    return r;
+}
+// loose -> weak form: multiply by 1 (internal form of 1 is 2^261 mod p)
+template <class C> DVN_HD Fe<C> fe_reduce_loose(const Fe<C>& a) { return fe_mul<C>(a, fe_one<C>()); }
+// x == 0 (mod p) for a loose x < 16p: x = k p with k = x_0 * p^-1 mod 2^29; k >= 16 settles it in three instructions
+template <class C> DVN_NOINLINE bool fe_is_zero_loose_slow(Fe<C> a) { return fe_is_zero<C>(fe_reduce_loose<C>(a)); }
+template <class C> DVN_HD bool fe_is_zero_loose(const Fe<C>& a) {
+    const u32 k = (a.v[0] * C::pinv) & LMASK;
+    if (__builtin_expect(k >= 16, 1)) return false;      // 1 - 2^-25 of the time
+    return fe_is_zero_loose_slow<C>(a);                   // real call: keeps the 162-mad reduction out of the hot loop
 }
 
 // x == 0 (mod p) for weak-form x: x is 0 or p
@@ -288,6 +362,8 @@ template <> struct Ops<Fp> {
         return z == 0; }
     static constexpr int WORDS = 8;   // external u32 words per element
     static constexpr bool OUTLINE = false;
+    static constexpr bool LAZY = true;    // Curve::acc_add_mixed uses the lazily reduced formulas
+    typedef FpCfg Cfg;
     static DVN_HD Fp load_internal(const u32* w) { u32 t[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) t[i] = w[i];
@@ -335,6 +411,7 @@ template <> struct Ops<Fp2> {
     static DVN_HD bool is_literal_zero(const Fp2& a) { return B::is_literal_zero(a.a0) && B::is_literal_zero(a.a1); }
     static constexpr int WORDS = 16;
     static constexpr bool OUTLINE = false;
+    static constexpr bool LAZY = false;
     static DVN_HD Fp2 load_internal(const u32* w) { return Fp2{B::load_internal(w), B::load_internal(w + 8)}; }
     static DVN_HD void store_internal(const Fp2& a, u32* w) { B::store_internal(a.a0, w); B::store_internal(a.a1, w + 8); }
     static DVN_HD Fp2 from_ext(const u32* w) { return Fp2{B::from_ext(w), B::from_ext(w + 8)}; }

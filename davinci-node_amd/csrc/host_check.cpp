@@ -72,6 +72,16 @@ void hc_g1_add_full(const uint32_t* a, const uint32_t* b, uint32_t* out) {
     G1::X pb2 = G1::add(G1::dbl(pb), G1::neg(pb));
     G1::affine_to_ext(G1::to_affine(G1::add(pa2, pb2)), out);
 }
+// sum_i (+/-) P_i through the lazily reduced accumulator of k_accumulate (sign bit 31 of idx[i] = negate)
+void hc_g1_acc_chain(const uint32_t* pts, const uint32_t* idx, size_t n, uint32_t* out) {
+    G1::X acc = G1::infinity();
+    for (size_t i = 0; i < n; ++i) {
+        G1::A p = G1::affine_from_ext(pts + 16 * (size_t)(idx[i] & 0x7fffffffu));
+        if (idx[i] & 0x80000000u) p = G1::neg(p);
+        acc = G1::acc_add_mixed(acc, p);
+    }
+    G1::affine_to_ext(G1::to_affine(G1::acc_normalize(acc)), out);
+}
 void hc_g2_add(const uint32_t* a, const uint32_t* b, uint32_t* out) {
     G2::affine_to_ext(G2::to_affine(G2::add_mixed(G2::from_affine(G2::affine_from_ext(a)), G2::affine_from_ext(b))), out);
 }

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(128) void k_accumulate(const u32* __restrict__ poin
         if (b_start >= pos0 && b_end <= pos1) dst = bucket_sums + ((size_t)w * nb + b) * Cv::XW;
         else if (b_start <= pos0) dst = edge_first + ((size_t)w * nseg + k) * Cv::XW;
         else dst = edge_last + ((size_t)w * nseg + k) * Cv::XW;
-        st_xyzz<Cv>(acc, dst);
+        st_xyzz<Cv>(Cv::acc_normalize(acc), dst);
         (void)end_x;
     };
     for (u32 x = pos0; x < pos1; ++x) {
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(128) void k_accumulate(const u32* __restrict__ poin
         const u32 e = src[x];
         A p = ld_affine<Cv>(points + (pts_off + (size_t)(e & ~SIGN_BIT)) * Cv::AW);
         if (e & SIGN_BIT) p = Cv::neg(p);
-        acc = Cv::add_mixed(acc, p);
+        acc = Cv::acc_add_mixed(acc, p);
     }
     flush(pos1);
 }
