@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--scalars", choices=["uniform", "witness"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=20)
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (NTT 2^24, Groth16 2^20)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -147,6 +148,42 @@ def main():
                          f"{dt:.2f} s wall; own C Pippenger (oracle/bn254_cpu.c), not gnark",
                "gpu_matches_on_sample": bool((got == want).all())}
 
+    # ---- secondary measurements (outside the timed region; N = 1 only): BASELINE configs 3 and 5 --------------
+    extras = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = {}
+        # config 3: Fr NTT 2^24 forward (DIF) + inverse (DIT), data resident in HBM; 64 B per element per transform
+        ln = 24
+        dom = ctx.domain(ln)
+        dx = ctx.synthetic_scalars(2, 0, 1 << ln)
+        x0 = np.empty((1 << ln, 4), dtype=np.uint64); ctx.d2h(x0, dx)
+        f_ms, i_ms = [], []
+        for _ in range(5):
+            ctx.ntt(dom, dx, False, pkg.DIF); f_ms.append(ctx.last_kernel_ms(0))
+            ctx.ntt(dom, dx, True, pkg.DIT); i_ms.append(ctx.last_kernel_ms(0))
+        x1 = np.empty_like(x0); ctx.d2h(x1, dx)
+        fi = float(np.median(f_ms) + np.median(i_ms))
+        extras["ntt_2^24_fwd_plus_inv"] = {"ms": round(fi, 4), "Melem_per_s": round(2 * (1 << ln) / fi / 1e3, 1),
+                                           "achieved_GBps": round(2 * (1 << ln) * 64 / (fi * 1e-3) / 1e9, 1),
+                                           "frac_of_hbm_peak": round(2 * (1 << ln) * 64 / (fi * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                           "round_trip_identity": bool((x0 == x1).all())}
+        ctx.free(dx); dom.free(); del x0, x1
+        # config 5 (single GPU): statetransition-shaped synthetic Groth16, n = 2^20 constraints, 8 public inputs + constant
+        cs = pkg.R1CS(7, 1 << 20, 9)
+        key = pkg.Groth16Key(ctx, cs, 3)
+        dw = ctx.to_device(cs.witness())
+        rs = np.array([[5, 0, 0, 0], [7, 0, 0, 0]], dtype=np.uint64)
+        key.prove(dw, rs[0], rs[1])
+        t0 = time.perf_counter()
+        for _ in range(5):
+            key.prove(dw, rs[0], rs[1])
+        dtp = (time.perf_counter() - t0) / 5
+        ms = key.last_ms()
+        extras["groth16_synthetic_2^20"] = {"proofs_per_s": round(1 / dtp, 3), "ms_per_proof": round(dtp * 1e3, 3),
+                                            "device_ms_computeH": round(ms["compute_h"], 3), "device_ms_5_msm": round(ms["msm"], 3),
+                                            "key_sizes": key.sizes, "witness": "resident in HBM; solve = sparse (A w, B w, C w) on device"}
+        ctx.free(dw); key.free(); cs.free()
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = n * args.steps / elapsed / 1e6
@@ -165,6 +202,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                          "kernel": "k_accumulate<G1>", "kernel_ms": round(acc, 4), "device_ms_per_step": round(float(np.mean(dev_ms)), 4)},
             "cpu_baseline": cpu,
+            "extras": extras,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
