@@ -80,6 +80,7 @@ def load_library():
         "dvn_groth16_pk_free": (i32, [vp, vp]),
         "dvn_groth16_prove": (i32, [vp, vp, vp, u32, vp, vp, vp]),
         "dvn_groth16_last_ms": (i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+        "dvn_groth16_proof_abi_encode": (i32, [vp, vp, vp, vp]),
         "dvn_prover_use_gpu": (i32, []),
         "dvn_prover_set_use_gpu": (None, [i32]),
         "dvn_prover_reload_env": (None, []),
@@ -104,7 +105,7 @@ EXPORTED_SYMBOLS = [
     "dvn_msm_plan", "dvn_msm_g1_windows", "dvn_msm_combine_g1", "dvn_ntt_domain", "dvn_ntt_domain_free", "dvn_ntt",
     "dvn_groth16_compute_h", "dvn_last_kernel_ms", "dvn_r1cs_synthetic", "dvn_r1cs_info", "dvn_r1cs_witness", "dvn_r1cs_free",
     "dvn_groth16_setup", "dvn_groth16_pk_info", "dvn_groth16_pk_free", "dvn_groth16_prove", "dvn_groth16_last_ms",
-    "dvn_prover_use_gpu", "dvn_prover_set_use_gpu", "dvn_prover_reload_env", "dvn_prover_set_prover", "dvn_prover_set_cpu_backend",
+    "dvn_groth16_proof_abi_encode", "dvn_prover_use_gpu", "dvn_prover_set_use_gpu", "dvn_prover_reload_env", "dvn_prover_set_prover", "dvn_prover_set_cpu_backend",
     "dvn_prover_last_backend", "dvn_prover_prove", "dvn_prover_setup",
 ]
 

@@ -451,3 +451,32 @@ extern "C" int32_t dvn_groth16_last_ms(const dvn_groth16_pk* pk, float* ms_h, fl
     if (ms_total) *ms_total = pk->ms_total;
     return DVN_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Solidity ABI image of a proof: /root/reference/solidity/solidity.go:29-73,85-116
+// (uint256[8] proof, uint256[2] commitments, uint256[2] commitmentPok), every word big-endian, G2 coordinates in
+// EIP-197 order (A1 before A0).  Host only.
+// ------------------------------------------------------------------------------------------------------
+static void fp_ext_to_be32(const u32* ext_words, uint8_t* out) {
+    u32 t[8], c[8];
+    memcpy(t, ext_words, 32);
+    fe_pack<FpCfg>(fe_canonical<FpCfg>(fe_mul<FpCfg>(fe_unpack<FpCfg>(t), fe_small<FpCfg>(32))), c);   // x*2^256 -> x
+    for (int i = 0; i < 8; ++i) {
+        const u32 w = c[7 - i];
+        out[4 * i] = (uint8_t)(w >> 24); out[4 * i + 1] = (uint8_t)(w >> 16); out[4 * i + 2] = (uint8_t)(w >> 8); out[4 * i + 3] = (uint8_t)w;
+    }
+}
+extern "C" int32_t dvn_groth16_proof_abi_encode(const uint64_t proof[32], const uint64_t commitment[8], const uint64_t commitment_pok[8],
+                                                uint8_t out[384]) {
+    if (!proof || !out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    const u32* p = (const u32*)proof;
+    const u32* ar = p; const u32* bs = p + 16; const u32* krs = p + 48;
+    fp_ext_to_be32(ar, out); fp_ext_to_be32(ar + 8, out + 32);
+    fp_ext_to_be32(bs + 8, out + 64);  fp_ext_to_be32(bs, out + 96);          // Bs.X.A1, Bs.X.A0
+    fp_ext_to_be32(bs + 24, out + 128); fp_ext_to_be32(bs + 16, out + 160);   // Bs.Y.A1, Bs.Y.A0
+    fp_ext_to_be32(krs, out + 192); fp_ext_to_be32(krs + 8, out + 224);
+    memset(out + 256, 0, 128);
+    if (commitment) { fp_ext_to_be32((const u32*)commitment, out + 256); fp_ext_to_be32((const u32*)commitment + 8, out + 288); }
+    if (commitment_pok) { fp_ext_to_be32((const u32*)commitment_pok, out + 320); fp_ext_to_be32((const u32*)commitment_pok + 8, out + 352); }
+    return DVN_OK;
+}

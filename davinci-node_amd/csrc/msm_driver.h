@@ -170,7 +170,7 @@ static int32_t msm_windows(dvn_ctx* ctx, const dvn_points* pts, size_t off, size
     DBG_SYNC("k_fix_heavy");
     k_bucket_reduce<Cv><<<W * bpw, 256, sh_bytes, st>>>(buckets, partials, nb, L, bpw);
     DBG_SYNC("k_bucket_reduce");
-    k_window_finalize<Cv><<<(W + 63) / 64, 64, 0, st>>>(partials, wsums, W, bpw);
+    k_window_finalize<Cv><<<W, 64, (size_t)64 * Cv::XW * 4, st>>>(partials, wsums, W, bpw);
     DBG_SYNC("k_window_finalize");
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev[1], st));

@@ -379,15 +379,19 @@ __global__ __launch_bounds__(256) void k_bucket_reduce(const u32* __restrict__ b
     tot = block_sum<Cv>(tot, sh);
     if (threadIdx.x == 0) st_xyzz<Cv>(tot, partials + (size_t)blockIdx.x * Cv::XW);
 }
+// one small block per window: tree-sum of the window's partial results
 template <class Cv>
-__global__ void k_window_finalize(const u32* __restrict__ partials, u32* __restrict__ window_sums, u32 nwin_local,
-                                  u32 blocks_per_window) {
+__global__ __launch_bounds__(64) void k_window_finalize(const u32* __restrict__ partials, u32* __restrict__ window_sums, u32 nwin_local,
+                                                        u32 blocks_per_window) {
     typedef typename Cv::X X;
-    const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= nwin_local) return;
+    extern __shared__ __align__(16) u32 sh[];
+    const u32 w = blockIdx.x;
     X acc = Cv::infinity();
-    for (u32 i = 0; i < blocks_per_window; ++i) acc = Cv::add(acc, ld_xyzz<Cv>(partials + ((size_t)w * blocks_per_window + i) * Cv::XW));
-    st_xyzz<Cv>(acc, window_sums + (size_t)w * Cv::XW);
+    for (u32 i = threadIdx.x; i < blocks_per_window; i += blockDim.x)
+        acc = Cv::add(acc, ld_xyzz<Cv>(partials + ((size_t)w * blocks_per_window + i) * Cv::XW));
+    acc = block_sum<Cv>(acc, sh);
+    if (threadIdx.x == 0) st_xyzz<Cv>(acc, window_sums + (size_t)w * Cv::XW);
+    (void)nwin_local;
 }
 
 }  // namespace dvn

@@ -134,6 +134,12 @@ int32_t dvn_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witn
 /* device time of the last dvn_groth16_prove: computeH part (incl. the matrix-vector "solve"), the five MSMs, total */
 int32_t dvn_groth16_last_ms(const dvn_groth16_pk* pk, float* ms_h, float* ms_msm, float* ms_total);
 
+/* Solidity ABI image (uint256[8], uint256[2], uint256[2]) of a proof, as /root/reference/solidity/solidity.go:29-73,
+ * 85-116 builds it for the on-chain verifier: big-endian words, G2 coordinates A1 before A0.
+ * commitment / commitment_pok: G1Affine images or NULL (zeros).  Host only. */
+int32_t dvn_groth16_proof_abi_encode(const uint64_t proof[32], const uint64_t commitment[8], const uint64_t commitment_pok[8],
+                                     uint8_t out[384]);
+
 /* ---- mirror of the reference's `prover` package (csrc/dvn_prover_pkg.hip) --------------------- */
 /* Same control flow as /root/reference/prover/prover_gpu.go:66-123: Prove -> prover func (SetProver seam) ->
  * defaultProver: if UseGPUProver (env GPU_PROVER in {true,y,1,yes}, prover/config.go:18-26) try the GPU and on ANY

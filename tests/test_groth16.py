@@ -73,3 +73,17 @@ def test_groth16_wrong_witness_changes_proof(ctx, pkg, opy, orc):
     _, want = orc.groth16_synthetic_expected(7, 500, 9, 3, mont(opy, 1), mont(opy, 2))
     assert not (got["Krs"] == want["Krs"]).all()
     key.free(); cs.free()
+
+
+def test_proof_abi_encoding_matches_reference_layout(pkg, opy, orc):
+    """solidity/solidity.go:29-73,85-116: [Ar.X, Ar.Y, Bs.X.A1, Bs.X.A0, Bs.Y.A1, Bs.Y.A0, Krs.X, Krs.Y] ++ commitments ++ pok."""
+    import ctypes as C
+    o = opy
+    L = pkg.load_library()
+    ar = o.g1_mul(o.G1_GEN, 12345); krs = o.g1_mul(o.G1_GEN, 99); bs = o.g2_mul(o.G2_GEN, 777); com = o.g1_mul(o.G1_GEN, 5)
+    proof = np.array(o.g1_to_limbs(ar) + o.g2_to_limbs(bs) + o.g1_to_limbs(krs), dtype=np.uint64)
+    cm = np.array(o.g1_to_limbs(com), dtype=np.uint64)
+    out = np.zeros(384, dtype=np.uint8)
+    assert L.dvn_groth16_proof_abi_encode(proof.ctypes.data, cm.ctypes.data, None, out.ctypes.data) == 0
+    words = [int.from_bytes(bytes(out[32 * i:32 * i + 32]), "big") for i in range(12)]
+    assert words == [ar[0], ar[1], bs[0][1], bs[0][0], bs[1][1], bs[1][0], krs[0], krs[1], com[0], com[1], 0, 0]
