@@ -34,8 +34,8 @@ struct dvn_groth16_pk {
     dvn_points *A = nullptr, *B = nullptr, *K = nullptr, *Z = nullptr, *B2 = nullptr;
     size_t nA = 0, nB = 0;
     u32 *d_idxA = nullptr, *d_idxB = nullptr;           // wires kept after infinity filtering (InfinityA/B)
-    G1::A alpha, beta, delta;
-    G2::A beta2, delta2;
+    dvn_host::HG1::X alpha, beta, delta;       // key constants in the host finishing arithmetic (host_fast.h)
+    dvn_host::HG2::X beta2, delta2;
     u32 *d_ptr[3] = {nullptr, nullptr, nullptr}, *d_idx[3] = {nullptr, nullptr, nullptr}, *d_coef[3] = {nullptr, nullptr, nullptr};
     u32 *d_w = nullptr, *d_abc = nullptr, *d_wA = nullptr, *d_wB = nullptr;   // per-proof buffers, allocated once
     float ms_h = 0, ms_msm = 0, ms_total = 0;
@@ -357,10 +357,15 @@ extern "C" int32_t dvn_groth16_setup(dvn_ctx* ctx, const dvn_r1cs* cs, uint64_t 
         HIP_TRY(hipMalloc((void**)&pk->d_wA, (pk->nA ? pk->nA : 1) * 32));
         HIP_TRY(hipMalloc((void**)&pk->d_wB, (pk->nB ? pk->nB : 1) * 32));
         // G1/G2 constants of the key
-        u32 kw[8];
-        fr_canonical_words(alpha, kw); pk->alpha = G1::to_affine(host_scalar_mul<G1>(g1, kw));
-        fr_canonical_words(beta, kw); pk->beta = G1::to_affine(host_scalar_mul<G1>(g1, kw)); pk->beta2 = G2::to_affine(host_scalar_mul<G2>(g2, kw));
-        fr_canonical_words(delta, kw); pk->delta = G1::to_affine(host_scalar_mul<G1>(g1, kw)); pk->delta2 = G2::to_affine(host_scalar_mul<G2>(g2, kw));
+        u32 kw[8], img1[G1::AW], img2[G2::AW];
+        G1::store_affine_internal(g1, img1); G2::store_affine_internal(g2, img2);
+        const dvn_host::HG1::X hg1 = dvn_host::HG1::load_device_affine(img1);
+        const dvn_host::HG2::X hg2 = dvn_host::HG2::load_device_affine(img2);
+        fr_canonical_words(alpha, kw); pk->alpha = dvn_host::HG1::normalize(dvn_host::HG1::mul_scalar(hg1, kw));
+        fr_canonical_words(beta, kw); pk->beta = dvn_host::HG1::normalize(dvn_host::HG1::mul_scalar(hg1, kw));
+        pk->beta2 = dvn_host::HG2::normalize(dvn_host::HG2::mul_scalar(hg2, kw));
+        fr_canonical_words(delta, kw); pk->delta = dvn_host::HG1::normalize(dvn_host::HG1::mul_scalar(hg1, kw));
+        pk->delta2 = dvn_host::HG2::normalize(dvn_host::HG2::mul_scalar(hg2, kw));
         return DVN_OK;
     };
     rc = body();
@@ -410,7 +415,9 @@ extern "C" int32_t dvn_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uin
         if (pk->nB) k_gather_fr<<<(unsigned)((pk->nB + 255) / 256), 256, 0, st>>>(pk->d_w, pk->d_idxB, pk->d_wB, pk->nB);
         HIP_TRY(hipGetLastError());
         // (6) the five MSMs
-        G1::X mA, mB, mK, mZ; G2::X mB2;
+        typedef dvn_host::HG1 H1;
+        typedef dvn_host::HG2 H2;
+        H1::X mA, mB, mK, mZ; H2::X mB2;
         TRY(dvn_internal_msm_g1_dev(ctx, pk->A, 0, pk->nA, pk->d_wA, &mA));
         TRY(dvn_internal_msm_g1_dev(ctx, pk->B, 0, pk->nB, pk->d_wB, &mB));
         TRY(dvn_internal_msm_g2_dev(ctx, pk->B2, 0, pk->nB, pk->d_wB, &mB2));
@@ -418,23 +425,25 @@ extern "C" int32_t dvn_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uin
         TRY(dvn_internal_msm_g1_dev(ctx, pk->Z, 0, n - 1, pk->d_abc, &mZ));              // h[:n-1] against Z[:n-1]
         HIP_TRY(hipEventRecord(e2, st));
         HIP_TRY(hipStreamSynchronize(st));
-        // (5)(7) blinding and assembly on the host: O(1) group operations
+        // (5)(7) blinding and assembly on the host: O(1) group operations (host_fast.h)
         const Fr r = fr_from_ext_words(r_mont), s = fr_from_ext_words(s_mont);
         u32 rw[8], sw[8], krw[8];
         fr_canonical_words(r, rw); fr_canonical_words(s, sw);
         fr_canonical_words(fe_neg<FrCfg>(fe_mul<FrCfg>(r, s)), krw);
-        G1::X ar = G1::add(G1::add_mixed(mA, pk->alpha), host_scalar_mul<G1>(pk->delta, rw));
-        G1::X bs1 = G1::add(G1::add_mixed(mB, pk->beta), host_scalar_mul<G1>(pk->delta, sw));
-        G2::X bs = G2::add(G2::add_mixed(mB2, pk->beta2), host_scalar_mul<G2>(pk->delta2, sw));
-        const G1::A ar_a = G1::to_affine(ar), bs1_a = G1::to_affine(bs1);
-        G1::X krs = G1::add(mK, mZ);
-        krs = G1::add(krs, host_scalar_mul<G1>(pk->delta, krw));
-        krs = G1::add(krs, host_scalar_mul<G1>(ar_a, sw));
-        krs = G1::add(krs, host_scalar_mul<G1>(bs1_a, rw));
-        u32* o = (u32*)proof_out;
-        G1::affine_to_ext(ar_a, o);
-        G2::affine_to_ext(G2::to_affine(bs), o + 16);
-        G1::affine_to_ext(G1::to_affine(krs), o + 48);
+        const H1::X ar = H1::normalize(H1::add(H1::add(mA, pk->alpha), H1::mul_scalar(pk->delta, rw)));
+        const H1::X bs1 = H1::normalize(H1::add(H1::add(mB, pk->beta), H1::mul_scalar(pk->delta, sw)));
+        const H2::X bs = H2::add(H2::add(mB2, pk->beta2), H2::mul_scalar(pk->delta2, sw));
+        H1::X krs = H1::add(mK, mZ);
+        krs = H1::add(krs, H1::mul_scalar(pk->delta, krw));
+        krs = H1::add(krs, H1::mul_scalar(ar, sw));
+        krs = H1::add(krs, H1::mul_scalar(bs1, rw));
+        uint64_t j1[12], j2[24];
+        H1::write_jac(ar, j1); memcpy(proof_out, j1, 64);
+        H2::write_jac(bs, j2); memcpy(proof_out + 8, j2, 128);
+        H1::write_jac(krs, j1); memcpy(proof_out + 24, j1, 64);
+        if (H1::is_inf(ar)) memset(proof_out, 0, 64);                 // gnark's affine infinity is (0, 0)
+        if (H2::is_inf(bs)) memset(proof_out + 8, 0, 128);
+        if (H1::is_inf(krs)) memset(proof_out + 24, 0, 64);
         HIP_TRY(hipEventElapsedTime(&pk->ms_h, e0, e1));
         HIP_TRY(hipEventElapsedTime(&pk->ms_msm, e1, e2));
         HIP_TRY(hipEventElapsedTime(&pk->ms_total, e0, e2));

@@ -12,6 +12,7 @@
 
 #include "../../include/dvn_prover.h"
 #include "bn254_curve.h"
+#include "host_fast.h"
 
 using namespace dvn;
 
@@ -131,9 +132,9 @@ static inline G2::A g2_generator() {   // EIP-197 generator, gnark Montgomery im
 
 
 // ---- internal cross-TU entry points (caller holds ctx->mu) -------------------------------------------------
-// MSM with DEVICE scalars, result as an internal xyzz point (dvn_msm_g1.hip / dvn_msm_g2.hip)
-int32_t dvn_internal_msm_g1_dev(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, G1::X* out);
-int32_t dvn_internal_msm_g2_dev(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, G2::X* out);
+// MSM with DEVICE scalars, result as a host (4x64-limb, R = 2^256) extended-Jacobian point (dvn_msm_g1.hip / dvn_msm_g2.hip)
+int32_t dvn_internal_msm_g1_dev(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, dvn_host::HG1::X* out);
+int32_t dvn_internal_msm_g2_dev(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, dvn_host::HG2::X* out);
 // computeH on three device vectors of n = 2^log_n elements (already zero padded); result left in da (dvn_ntt.hip)
 int32_t dvn_internal_compute_h_dev(dvn_ctx* ctx, const dvn_domain* dom, u32* da, u32* db, u32* dc);
 uint32_t dvn_internal_domain_log_n(const dvn_domain* dom);

@@ -48,7 +48,7 @@ extern "C" int32_t dvn_msm_combine_g1(dvn_ctx* ctx, const uint64_t* window_sums,
                     : G1::X{Ops<Fp>::from_ext(in + w * 32), Ops<Fp>::from_ext(in + w * 32 + 8), Ops<Fp>::from_ext(in + w * 32 + 16), Ops<Fp>::from_ext(in + w * 32 + 24)};
         G1::store_xyzz_internal(p, sums.data() + (size_t)w * G1::XW);
     }
-    write_jac<G1>(horner<G1>(sums.data(), nwin, window_bits), out_jac);
+    dvn_host::HG1::write_jac(dvn_host::HG1::horner(sums.data(), nwin, window_bits), out_jac);
     return DVN_OK;
 }
 
@@ -90,7 +90,7 @@ extern "C" int32_t dvn_scalars_synthetic(dvn_ctx* ctx, uint64_t seed, int kind, 
     return DVN_OK;
 }
 
-int32_t dvn_internal_msm_g1_dev(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, G1::X* out) {
+int32_t dvn_internal_msm_g1_dev(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, dvn_host::HG1::X* out) {
     if (pts->curve != 1) return fail(DVN_ERR_INVALID_ARG, "point set is not G1");
     return msm_dev_xyzz<G1>(ctx, pts, off, n, d_scalars, out);
 }

@@ -13,7 +13,7 @@ int32_t dvn_internal_points_download_g2(dvn_ctx* ctx, const dvn_points* pts, siz
     return points_download<G2>(ctx, pts, off, n, xy);
 }
 
-int32_t dvn_internal_msm_g2_dev(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, G2::X* out) {
+int32_t dvn_internal_msm_g2_dev(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, dvn_host::HG2::X* out) {
     if (pts->curve != 2) return fail(DVN_ERR_INVALID_ARG, "point set is not G2");
     return msm_dev_xyzz<G2>(ctx, pts, off, n, d_scalars, out);
 }

@@ -3,6 +3,7 @@
 #pragma once
 #include "dvn_internal.h"
 #include "msm_kernels.h"
+#include "host_fast.h"
 
 // ------------------------------------------------------------------------------------------------------
 // points
@@ -202,15 +203,19 @@ template <class Cv> static void write_jac(const typename Cv::X& p, uint64_t* out
     O::to_ext(a.x, w); O::to_ext(a.y, w + FW); O::to_ext(O::one(), w + 2 * FW);
 }
 
-// device scalars -> internal xyzz (caller holds the lock)
+template <class Cv> struct FastHost;
+template <> struct FastHost<G1> { typedef dvn_host::HG1 G; };
+template <> struct FastHost<G2> { typedef dvn_host::HG2 G; };
+
+// device scalars -> host (4x64-limb) extended-Jacobian point (caller holds the lock)
 template <class Cv>
-static int32_t msm_dev_xyzz(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, typename Cv::X* out) {
+static int32_t msm_dev_xyzz(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, typename FastHost<Cv>::G::X* out) {
     if (off > pts->n || n > pts->n - off) return fail(DVN_ERR_INVALID_ARG, "len(points) != len(scalars): range [%zu, %zu) outside point set of %zu", off, off + n, pts->n);
-    if (n == 0) { *out = Cv::infinity(); return DVN_OK; }
+    if (n == 0) { *out = FastHost<Cv>::G::infinity(); return DVN_OK; }
     u32 c, nwin; msm_plan(n, &c, &nwin);
     std::vector<u32> sums((size_t)nwin * Cv::XW);
     TRY(msm_windows<Cv>(ctx, pts, off, n, (const uint64_t*)d_scalars, DVN_MSM_SCALARS_ON_DEVICE, c, nwin, 0, nwin, sums.data()));
-    *out = horner<Cv>(sums.data(), nwin, c);
+    *out = FastHost<Cv>::G::horner(sums.data(), nwin, c);
     return DVN_OK;
 }
 
@@ -221,11 +226,12 @@ static int32_t msm_full(dvn_ctx* ctx, const dvn_points* pts, int curve, size_t o
     if (pts->curve != curve) return fail(DVN_ERR_INVALID_ARG, "point set is G%d, call is G%d", pts->curve, curve);
     if (off > pts->n || n > pts->n - off) return fail(DVN_ERR_INVALID_ARG, "len(points) != len(scalars): range [%zu, %zu) outside point set of %zu", off, off + n, pts->n);
     std::lock_guard<std::mutex> lk(ctx->mu);
-    if (n == 0) { write_jac<Cv>(Cv::infinity(), out_jac); ctx->last_ms[0] = ctx->last_ms[1] = 0.f; return DVN_OK; }
+    typedef typename FastHost<Cv>::G HG;
+    if (n == 0) { HG::write_jac(HG::infinity(), out_jac); ctx->last_ms[0] = ctx->last_ms[1] = 0.f; return DVN_OK; }
     u32 c, nwin; msm_plan(n, &c, &nwin);
     std::vector<u32> sums((size_t)nwin * Cv::XW);
     TRY(msm_windows<Cv>(ctx, pts, off, n, scalars, flags, c, nwin, 0, nwin, sums.data()));
-    write_jac<Cv>(horner<Cv>(sums.data(), nwin, c), out_jac);
+    HG::write_jac(HG::horner(sums.data(), nwin, c), out_jac);     // MSB-first window combine on the host (host_fast.h)
     return DVN_OK;
 }
 
