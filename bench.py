@@ -30,6 +30,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_PER_PAIR = 96            # 32 B scalar + 64 B affine point, SURVEY.md §8d
+# secondary (integer-issue) roofline of the dominant kernel -- context only, the contract's roofline is the HBM one:
+MADS_PER_ADD = 1467            # v_mad_u64_u32 per XYZZ mixed addition in k_accumulate's loop body (counted in the ISA)
+MAD_PEAK_PER_S = 35.4e12       # chip-wide v_mad_u64_u32 lane-op/s measured by tools/microbench (profiles/r01_instr_rate_microbench.txt)
 
 
 def main():
@@ -72,12 +75,15 @@ def main():
     ctx = pkg.Context(dev_index)
 
     n = 1 << args.log_n
-    c, nwin = ctx.msm_plan(n)
+    c, nwin = ctx.msm_plan(n)                                            # re-read below once the point set exists
+    win_lo_all, win_hi_all = rank * nwin // world, (rank + 1) * nwin // world      # windows this rank accumulates
 
     # ---- inputs resident in HBM before the timed region (generated ON the device by the library) -------------
     kind = 0 if args.scalars == "uniform" else 1
     pts = ctx.synthetic_g1(0xDA71C1, n)                                  # synthetic SRS  P_i = P0 + i*D
     scal_dev = ctx.synthetic_scalars(1, kind, n)                         # n x 32 B Montgomery scalars in HBM
+    c, nwin, _ = ctx.msm_plan_points(pts, n)
+    win_lo_all, win_hi_all = rank * nwin // world, (rank + 1) * nwin // world
 
     from davinci_node_amd import sharding
 
@@ -200,7 +206,13 @@ def main():
                        "inputs": "points + scalars resident in HBM", "result_checked": check},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                         "kernel": "k_accumulate<G1>", "kernel_ms": round(acc, 4), "device_ms_per_step": round(float(np.mean(dev_ms)), 4)},
+                         "kernel": "k_accumulate<G1>", "kernel_ms": round(acc, 4), "device_ms_per_step": round(float(np.mean(dev_ms)), 4),
+                         "int_issue_context": {"note": "kernel is v_mad_u64_u32-issue bound, not HBM bound (DESIGN.md §4)",
+                                               "mixed_additions_per_launch": n * (win_hi_all - win_lo_all),
+                                               "mad_per_addition": MADS_PER_ADD,
+                                               "achieved_Tmad_per_s": round(n * (win_hi_all - win_lo_all) * MADS_PER_ADD / (acc * 1e-3) / 1e12, 2),
+                                               "measured_peak_Tmad_per_s": MAD_PEAK_PER_S / 1e12,
+                                               "frac": round(n * (win_hi_all - win_lo_all) * MADS_PER_ADD / (acc * 1e-3) / MAD_PEAK_PER_S, 4)}},
             "cpu_baseline": cpu,
             "extras": extras,
         }

@@ -58,12 +58,14 @@ def load_library():
         "dvn_points_synthetic_g1": (i32, [vp, u64, sz, C.POINTER(vp)]),
         "dvn_points_synthetic_g2": (i32, [vp, u64, sz, C.POINTER(vp)]),
         "dvn_scalars_synthetic": (i32, [vp, u64, C.c_int, sz, vp]),
+        "dvn_points_set_expanded": (i32, [vp, vp, u32]),
         "dvn_points_download": (i32, [vp, vp, sz, sz, vp]),
         "dvn_points_len": (sz, [vp]),
         "dvn_points_free": (i32, [vp, vp]),
         "dvn_msm_g1": (i32, [vp, vp, sz, sz, vp, u32, vp]),
         "dvn_msm_g2": (i32, [vp, vp, sz, sz, vp, u32, vp]),
         "dvn_msm_plan": (i32, [sz, C.POINTER(u32), C.POINTER(u32)]),
+        "dvn_msm_plan_points": (i32, [vp, sz, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),
         "dvn_msm_g1_windows": (i32, [vp, vp, sz, sz, vp, u32, u32, u32, vp]),
         "dvn_msm_combine_g1": (i32, [vp, vp, u32, u32, vp]),
         "dvn_ntt_domain": (i32, [vp, u32, C.POINTER(vp)]),
@@ -101,8 +103,8 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "dvn_init", "dvn_shutdown", "dvn_last_error", "dvn_version", "dvn_malloc", "dvn_free", "dvn_memcpy_h2d",
     "dvn_memcpy_d2h", "dvn_synchronize", "dvn_points_upload_g1", "dvn_points_upload_g2", "dvn_points_synthetic_g1",
-    "dvn_points_synthetic_g2", "dvn_scalars_synthetic", "dvn_points_download", "dvn_points_len", "dvn_points_free", "dvn_msm_g1", "dvn_msm_g2",
-    "dvn_msm_plan", "dvn_msm_g1_windows", "dvn_msm_combine_g1", "dvn_ntt_domain", "dvn_ntt_domain_free", "dvn_ntt",
+    "dvn_points_synthetic_g2", "dvn_scalars_synthetic", "dvn_points_set_expanded", "dvn_points_download", "dvn_points_len", "dvn_points_free", "dvn_msm_g1", "dvn_msm_g2",
+    "dvn_msm_plan", "dvn_msm_plan_points", "dvn_msm_g1_windows", "dvn_msm_combine_g1", "dvn_ntt_domain", "dvn_ntt_domain_free", "dvn_ntt",
     "dvn_groth16_compute_h", "dvn_last_kernel_ms", "dvn_r1cs_synthetic", "dvn_r1cs_info", "dvn_r1cs_witness", "dvn_r1cs_free",
     "dvn_groth16_setup", "dvn_groth16_pk_info", "dvn_groth16_pk_free", "dvn_groth16_prove", "dvn_groth16_last_ms",
     "dvn_groth16_proof_abi_encode", "dvn_prover_use_gpu", "dvn_prover_set_use_gpu", "dvn_prover_reload_env", "dvn_prover_set_prover", "dvn_prover_set_cpu_backend",
@@ -131,6 +133,10 @@ class Points:
         out = np.zeros((n, 8 if self.curve == 1 else 16), dtype=np.uint64)
         self.ctx._chk(self.ctx.L.dvn_points_download(self.ctx.h, self.handle, off, n, _host(out)))
         return out
+
+    def set_expanded(self, window_bits: int):
+        """Rebuild as an expanded table (row w = 2^(window_bits w) P); 0 collapses it."""
+        self.ctx._chk(self.ctx.L.dvn_points_set_expanded(self.ctx.h, self.handle, window_bits))
 
     def free(self):
         if self.handle:
@@ -240,6 +246,12 @@ class Context:
         rc = self.L.dvn_msm_plan(n, C.byref(c), C.byref(w))
         self._chk(rc)
         return c.value, w.value
+
+    def msm_plan_points(self, pts: Points, n: int):
+        """(window_bits, nwin, combine_bits) for an n-scalar MSM over this point set."""
+        c, w, cb = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._chk(self.L.dvn_msm_plan_points(pts.handle, n, C.byref(c), C.byref(w), C.byref(cb)))
+        return c.value, w.value, cb.value
 
     def msm_g1_windows(self, pts: Points, scalars, win_lo: int, win_hi: int, off: int = 0, n: int | None = None) -> np.ndarray:
         sp, ns, fl = self._scalars(scalars, n)

@@ -236,16 +236,18 @@ static int32_t fixed_base_points(dvn_ctx* ctx, const typename Cv::A& gen, const 
     dvn_points* p = new (std::nothrow) dvn_points();
     if (!p) return fail(DVN_ERR_OOM, "host allocation failed");
     p->curve = curve; p->n = count;
+    expand_plan(curve, count, &p->expand_c, &p->nexp);
     u32 *table = nullptr, *dgen = nullptr;
     u32 hg[Cv::AW];
     Cv::store_affine_internal(gen, hg);
-    hipError_t e = hipMalloc((void**)&p->d, count ? count * Cv::AW * 4 : 16);
+    hipError_t e = hipMalloc((void**)&p->d, count ? count * Cv::AW * 4 * p->nexp : 16);
     if (e == hipSuccess) e = hipMalloc((void**)&table, (size_t)32 * 256 * Cv::AW * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&dgen, sizeof(hg));
     if (e == hipSuccess) e = hipMemcpy(dgen, hg, sizeof(hg), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         k_fb_table<Cv><<<32 * 256 / 64, 64, 0, ctx->stream>>>(table, dgen);
         if (count) k_fixed_base<Cv><<<(unsigned)((count + 63) / 64), 64, 0, ctx->stream>>>(table, d_scalars, p->d, count);
+        if (count && p->expand_c) k_points_expand<Cv><<<(unsigned)((count + 63) / 64), 64, 0, ctx->stream>>>(p->d, count, p->expand_c, p->nexp);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

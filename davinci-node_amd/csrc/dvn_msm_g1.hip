@@ -11,19 +11,33 @@ extern "C" int32_t dvn_msm_g1(dvn_ctx* ctx, const dvn_points* pts, size_t off, s
     return msm_full<G1>(ctx, pts, 1, off, n, scalars, flags, out_jac);
 }
 
+// (window_bits, nwin, combine_bits) the library will use for an n-scalar MSM over this point set.  Expanded sets
+//  have pts-specific windows and combine_bits = 0: partial results of window ranges simply add up.
+extern "C" int32_t dvn_msm_plan_points(const dvn_points* pts, size_t n, uint32_t* window_bits, uint32_t* nwin, uint32_t* combine_bits) {
+    if (!pts || !window_bits || !nwin || !combine_bits) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    if (use_expanded(pts, n)) { *window_bits = pts->expand_c; *nwin = pts->nexp; *combine_bits = 0; return DVN_OK; }
+    msm_plan(n, window_bits, nwin);
+    *combine_bits = *window_bits;
+    return DVN_OK;
+}
 extern "C" int32_t dvn_msm_g1_windows(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
                                       uint32_t win_lo, uint32_t win_hi, uint64_t* window_sums) {
     TRY(enter(ctx));
     if (!pts || !window_sums || (!scalars && n)) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (pts->curve != 1) return fail(DVN_ERR_INVALID_ARG, "point set is not G1");
     if (off > pts->n || n > pts->n - off) return fail(DVN_ERR_INVALID_ARG, "len(points) != len(scalars)");
-    u32 c, nwin; msm_plan(n, &c, &nwin);
+    const bool expanded = use_expanded(pts, n);
+    u32 c, nwin;
+    if (expanded) { c = pts->expand_c; nwin = pts->nexp; } else msm_plan(n, &c, &nwin);
     if (win_lo > win_hi || win_hi > nwin) return fail(DVN_ERR_INVALID_ARG, "window range [%u, %u) outside [0, %u)", win_lo, win_hi, nwin);
     const u32 W = win_hi - win_lo;
     if (W == 0) return DVN_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
     std::vector<u32> sums((size_t)W * G1::XW, 0u);
-    if (n) TRY(msm_windows<G1>(ctx, pts, off, n, scalars, flags, c, nwin, win_lo, win_hi, sums.data()));
+    if (n) {
+        if (expanded) TRY(msm_expanded<G1>(ctx, pts, off, n, scalars, flags, win_lo, win_hi, sums.data()));   // slot 0 = partial sum
+        else TRY(msm_windows<G1>(ctx, pts, off, n, scalars, flags, c, nwin, win_lo, win_hi, sums.data()));
+    }
     // export as external-Montgomery (X, Y, ZZ, ZZZ); infinity = all zero
     u32* o = (u32*)window_sums;
     for (u32 w = 0; w < W; ++w) {
@@ -34,11 +48,10 @@ extern "C" int32_t dvn_msm_g1_windows(dvn_ctx* ctx, const dvn_points* pts, size_
     }
     return DVN_OK;
 }
-
 extern "C" int32_t dvn_msm_combine_g1(dvn_ctx* ctx, const uint64_t* window_sums, uint32_t nwin, uint32_t window_bits, uint64_t out_jac[12]) {
     (void)ctx;   /* pure host computation: ctx may be NULL (CPU-side tests of the sharded path) */
     if (!window_sums || !out_jac) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
-    if (window_bits == 0 || window_bits > 16 || nwin == 0 || nwin > 64) return fail(DVN_ERR_INVALID_ARG, "bad window layout");
+    if (window_bits > 24 || nwin == 0 || nwin > 64) return fail(DVN_ERR_INVALID_ARG, "bad window layout");   /* window_bits 0 = plain sum */
     const u32* in = (const u32*)window_sums;
     std::vector<u32> sums((size_t)nwin * G1::XW);
     for (u32 w = 0; w < nwin; ++w) {
@@ -72,6 +85,13 @@ extern "C" int32_t dvn_points_download(dvn_ctx* ctx, const dvn_points* pts, size
     return pts->curve == 1 ? points_download<G1>(ctx, pts, off, n, xy) : dvn_internal_points_download_g2(ctx, pts, off, n, xy);
 }
 
+int32_t dvn_internal_points_set_expanded_g2(dvn_ctx* ctx, dvn_points* pts, u32 c);   // dvn_msm_g2.hip
+extern "C" int32_t dvn_points_set_expanded(dvn_ctx* ctx, dvn_points* pts, uint32_t window_bits) {
+    TRY(enter(ctx));
+    if (!pts) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return pts->curve == 1 ? points_set_expanded<G1>(ctx, pts, window_bits) : dvn_internal_points_set_expanded_g2(ctx, pts, window_bits);
+}
 extern "C" int32_t dvn_msm_plan(size_t n, uint32_t* window_bits, uint32_t* nwin) {
     if (!window_bits || !nwin) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     msm_plan(n, window_bits, nwin);

@@ -17,3 +17,5 @@ int32_t dvn_internal_msm_g2_dev(dvn_ctx* ctx, const dvn_points* pts, size_t off,
     if (pts->curve != 2) return fail(DVN_ERR_INVALID_ARG, "point set is not G2");
     return msm_dev_xyzz<G2>(ctx, pts, off, n, d_scalars, out);
 }
+
+int32_t dvn_internal_points_set_expanded_g2(dvn_ctx* ctx, dvn_points* pts, u32 c) { return points_set_expanded<G2>(ctx, pts, c); }

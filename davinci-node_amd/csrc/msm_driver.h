@@ -16,13 +16,15 @@ template <class Cv> static int32_t points_upload(dvn_ctx* ctx, const uint64_t* x
     dvn_points* p = new (std::nothrow) dvn_points();
     if (!p) return fail(DVN_ERR_OOM, "host allocation failed");
     p->curve = curve; p->n = n;
+    expand_plan(curve, n, &p->expand_c, &p->nexp);
     size_t bytes = n * Cv::AW * 4;
-    hipError_t e = hipMalloc((void**)&p->d, bytes ? bytes : 16);
+    hipError_t e = hipMalloc((void**)&p->d, bytes ? bytes * p->nexp : 16);
     if (e != hipSuccess) { delete p; (void)hipGetLastError(); return fail(DVN_ERR_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
     if (n) {
         e = hipMemcpyAsync(p->d, xy, bytes, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) {
             k_points_to_internal<Cv><<<(unsigned)((n + 127) / 128), 128, 0, ctx->stream>>>(p->d, n);
+            if (p->expand_c) k_points_expand<Cv><<<(unsigned)((n + 63) / 64), 64, 0, ctx->stream>>>(p->d, n, p->expand_c, p->nexp);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // caller's buffer is free after return
@@ -44,14 +46,16 @@ template <class Cv> static int32_t points_synthetic(dvn_ctx* ctx, uint64_t seed,
     dvn_points* p = new (std::nothrow) dvn_points();
     if (!p) return fail(DVN_ERR_OOM, "host allocation failed");
     p->curve = curve; p->n = n;
+    expand_plan(curve, n, &p->expand_c, &p->nexp);
     u32* dbs = nullptr;
-    hipError_t e = hipMalloc((void**)&p->d, n ? n * Cv::AW * 4 : 16);
+    hipError_t e = hipMalloc((void**)&p->d, n ? n * Cv::AW * 4 * p->nexp : 16);
     if (e == hipSuccess) e = hipMalloc((void**)&dbs, sizeof(hb));
     if (e == hipSuccess) e = hipMemcpyAsync(dbs, hb, sizeof(hb), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && n) {
         const u32 chunk = 16;
         size_t threads = (n + chunk - 1) / chunk;
         k_points_progression<Cv><<<(unsigned)((threads + 63) / 64), 64, 0, ctx->stream>>>(p->d, n, dbs, chunk);
+        if (p->expand_c) k_points_expand<Cv><<<(unsigned)((n + 63) / 64), 64, 0, ctx->stream>>>(p->d, n, p->expand_c, p->nexp);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -87,15 +91,33 @@ static void msm_plan(size_t n, u32* c_out, u32* nwin_out) {
     *c_out = best; *nwin_out = 254 / best + 1;
 }
 
+// Segment length for k_accumulate: every lane executes exactly `seg` additions.  Measured (tools/gpu_seg.py, 2^22):
+// anything in 32..128 is within 3 %, longer segments lose to the tail of the last wave round, shorter ones to the
+// edge partials -- aim at >= 4 rounds of the resident lanes, clamp to [16, 128].
+template <class Cv> static u32 pick_segment(size_t total) {
+    static size_t slots = 0;                         // resident lanes of k_accumulate<Cv> on this device
+    if (!slots) {
+        int blocks = 0, dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, (const void*)k_accumulate<Cv>, 128, 0) == hipSuccess && blocks > 0)
+            slots = (size_t)prop.multiProcessorCount * blocks * 128;
+        else { (void)hipGetLastError(); slots = 196608; }
+    }
+    static const int forced = []() { const char* v = getenv("DVN_MSM_SEG"); return v ? atoi(v) : 0; }();
+    if (forced >= 16) return (u32)forced;
+    size_t seg = total / (slots * 4);
+    if (seg < 16) seg = 16;
+    if (seg > 128) seg = 128;
+    return (u32)seg;
+}
+
 // window sums for windows [win_lo, win_hi) -> host, internal packed xyzz images (XW words each)
 template <class Cv>
 static int32_t msm_windows(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
                            u32 c, u32 nwin, u32 win_lo, u32 win_hi, u32* host_sums) {
     const u32 W = win_hi - win_lo;
     const u32 nb = 1u << (c - 1);
-    // segment length: keep >= ~256K lanes in flight, at most 128 additions per lane
-    u32 seg = 16;
-    while (seg < 128 && (double)n * W / seg > 262144.0) seg <<= 1;
+    const u32 seg = pick_segment<Cv>((size_t)n * W);
     const u32 nseg = (u32)((n + seg - 1) / seg);
     const u32 L = 8;                                               // buckets per thread in the reduction (latency-bound: keep chains short)
     const u32 bpw = (nb + 256 * L - 1) / (256 * L);                // reduction blocks per window
@@ -182,6 +204,127 @@ static int32_t msm_windows(dvn_ctx* ctx, const dvn_points* pts, size_t off, size
     return DVN_OK;
 }
 
+// --------------------------------------------------------------------------------------------------------------------
+// Expanded-table MSM (msm_kernels.h "Expanded point sets"): virtual windows [win_lo, win_hi) of the pts->nexp windows of
+// width pts->expand_c, all accumulated into ONE bucket set.  host_sum receives ONE internal xyzz image: the partial
+// result of these windows, window weights included (partial results of different window ranges simply add up).
+// --------------------------------------------------------------------------------------------------------------------
+static inline bool use_expanded(const dvn_points* pts, size_t n) {
+    return pts->expand_c != 0 && n >= ((size_t)1 << 15) && n * 4 >= pts->n;
+}
+template <class Cv>
+static int32_t msm_expanded(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
+                            u32 win_lo, u32 win_hi, u32* host_sum) {
+    const u32 c = pts->expand_c, W = win_hi - win_lo;
+    const u32 nb = 1u << (c - 1), hb = nb >> LOB;
+    const size_t total = (size_t)W * n;                              // upper bound on the number of entries
+    if (total >= ((size_t)1 << 31) || (size_t)pts->nexp * pts->n >= ((size_t)1 << 31)) return fail(DVN_ERR_INVALID_ARG, "MSM too large for 31-bit entry references");
+    const u32 seg = pick_segment<Cv>(total);
+    const u32 nseg = (u32)((total + seg - 1) / seg);
+    const u32 L = 8;
+    const u32 bpw = (nb + 256 * L - 1) / (256 * L);
+    const u32 heavy_cap = (u32)(nseg / (FIX_LIGHT - 1) + 1);
+    const u32 tile_len = 65536;
+    const u32 ntiles = (u32)((total + tile_len - 1) / tile_len);
+    const bool on_dev = flags & DVN_MSM_SCALARS_ON_DEVICE;
+
+    CarverSize cs;
+    if (!on_dev) cs.take(n * 32);
+    cs.take(total * 4); cs.take(total * 4); cs.take(total * 2); cs.take(total * 4);    // digits, p1_ref, p1_lo, sorted
+    cs.take((size_t)ntiles * hb * 4); cs.take((size_t)(2 * hb + 2) * 4);                 // hist1; bin_total, bin_base
+    cs.take((size_t)nb * 4 * 2); cs.take(16);                                            // counts, offsets; totals + heavy_count
+    cs.take((size_t)heavy_cap * 4);
+    cs.take((size_t)nb * Cv::XW * 4);
+    cs.take((size_t)nseg * Cv::XW * 4); cs.take((size_t)nseg * Cv::XW * 4);
+    cs.take((size_t)bpw * Cv::XW * 4); cs.take((size_t)Cv::XW * 4);
+    TRY(ensure_ws(ctx, cs.off + 8192));
+    Carver cv(ctx->ws);
+    const u32* d_scalars;
+    if (!on_dev) {
+        u32* tmp = cv.take<u32>(n * 8);
+        HIP_TRY(hipMemcpyAsync(tmp, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+        d_scalars = tmp;
+    } else d_scalars = (const u32*)scalars;
+    int* digits = cv.take<int>(total);
+    u32* p1_ref = cv.take<u32>(total);
+    unsigned short* p1_lo = cv.take<unsigned short>(total);
+    u32* sorted = cv.take<u32>(total);
+    u32* hist1 = cv.take<u32>((size_t)ntiles * hb);
+    u32* bin_total = cv.take<u32>(2 * hb + 2);
+    u32* bin_base = bin_total + hb;
+    u32* counts = cv.take<u32>((size_t)nb * 2);
+    u32* offsets = counts + nb;
+    u32* totals = cv.take<u32>(4);
+    u32* heavy_count = totals + 1;
+    u32* heavy_list = cv.take<u32>(heavy_cap);
+    u32* buckets = cv.take<u32>((size_t)nb * Cv::XW);
+    u32* edge_first = cv.take<u32>((size_t)nseg * Cv::XW);
+    u32* edge_last = cv.take<u32>((size_t)nseg * Cv::XW);
+    u32* partials = cv.take<u32>((size_t)bpw * Cv::XW);
+    u32* wsum = cv.take<u32>(Cv::XW);
+
+    hipStream_t st = ctx->stream;
+    static const bool dbg = getenv("DVN_DEBUG_SYNC") != nullptr;
+    if (dbg) { fprintf(stderr, "[dvn] msm(expanded) n=%zu c=%u W=%u nb=%u hb=%u seg=%u nseg=%u ntiles=%u ws=%zu\n", n, c, W, nb, hb, seg, nseg, ntiles, cs.off); fflush(stderr); }
+    HIP_TRY(hipEventRecord(ctx->ev[0], st));
+    HIP_TRY(hipMemsetAsync(totals, 0, 16, st));
+    k_digits32<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_scalars, n, c, win_lo, win_hi, digits);
+    DBG_SYNC("k_digits32");
+    k_p1_hist<<<ntiles, 1024, (size_t)hb * 4, st>>>(digits, total, tile_len, hb, hist1);
+    DBG_SYNC("k_p1_hist");
+    k_p1_offsets<<<hb, 1024, 0, st>>>(hist1, bin_total, hb, ntiles);
+    DBG_SYNC("k_p1_offsets");
+    k_p1_scan<<<1, 1024, 0, st>>>(bin_total, bin_base, totals, hb);
+    DBG_SYNC("k_p1_scan");
+    k_p1_scatter<<<ntiles, 1024, (size_t)hb * 4, st>>>(digits, total, n, tile_len, hb, win_lo, (u32)pts->n, (u32)off, hist1, bin_base, p1_ref, p1_lo);
+    DBG_SYNC("k_p1_scatter");
+    k_p2_sort<<<hb, 1u << LOB, 0, st>>>(bin_base, p1_ref, p1_lo, sorted, counts, offsets);
+    DBG_SYNC("k_p2_sort");
+    HIP_TRY(hipEventRecord(ctx->ev[2], st));
+    k_accumulate<Cv><<<(unsigned)(((size_t)nseg + 127) / 128), 128, 0, st>>>(pts->d, 0, sorted, offsets, counts, totals, buckets,
+                                                                          edge_first, edge_last, total, nb, seg, nseg, 1);
+    DBG_SYNC("k_accumulate");
+    HIP_TRY(hipEventRecord(ctx->ev[3], st));
+    k_fix<Cv><<<(unsigned)(((size_t)nb + 127) / 128), 128, 0, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list,
+                                                                 heavy_count, 1, nb, seg, nseg, heavy_cap);
+    DBG_SYNC("k_fix");
+    const size_t sh_bytes = (size_t)256 * Cv::XW * 4;
+    k_fix_heavy<Cv><<<512, 256, sh_bytes, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list, heavy_count, nb, seg, nseg, heavy_cap);
+    DBG_SYNC("k_fix_heavy");
+    k_bucket_reduce<Cv><<<bpw, 256, sh_bytes, st>>>(buckets, partials, nb, L, bpw);
+    DBG_SYNC("k_bucket_reduce");
+    k_window_finalize<Cv><<<1, 64, (size_t)64 * Cv::XW * 4, st>>>(partials, wsum, 1, bpw);
+    DBG_SYNC("k_window_finalize");
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev[1], st));
+    HIP_TRY(hipMemcpyAsync(host_sum, wsum, (size_t)Cv::XW * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipEventElapsedTime(&ctx->last_ms[0], ctx->ev[0], ctx->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ctx->last_ms[1], ctx->ev[2], ctx->ev[3]));
+    return DVN_OK;
+}
+
+// (re)build the expanded table of an existing set for window size c (0 = back to a plain set)
+template <class Cv> static int32_t points_set_expanded(dvn_ctx* ctx, dvn_points* p, u32 c) {
+    if (c != 0 && (c < 11 || c > 24)) return fail(DVN_ERR_INVALID_ARG, "window_bits must be 0 or in [11, 24]");
+    const u32 nexp = c ? 254 / c + 1 : 1;
+    if ((size_t)nexp * p->n >= ((size_t)1 << 31)) return fail(DVN_ERR_INVALID_ARG, "expanded table too large");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    u32* nd = nullptr;
+    const size_t row = p->n * Cv::AW * 4;
+    HIP_TRY(hipMalloc((void**)&nd, row ? row * nexp : 16));
+    hipError_t e = row ? hipMemcpyAsync(nd, p->d, row, hipMemcpyDeviceToDevice, ctx->stream) : hipSuccess;
+    if (e == hipSuccess && c && p->n) {
+        k_points_expand<Cv><<<(unsigned)((p->n + 63) / 64), 64, 0, ctx->stream>>>(nd, p->n, c, nexp);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(nd); (void)hipGetLastError(); return fail(DVN_ERR_DEVICE, "expansion failed: %s", hipGetErrorString(e)); }
+    (void)hipFree(p->d);
+    p->d = nd; p->expand_c = c; p->nexp = nexp;
+    return DVN_OK;
+}
+
 template <class Cv> static typename Cv::X horner(const u32* sums /* nwin * XW internal */, u32 nwin, u32 c) {
     typename Cv::X acc = Cv::infinity();
     for (int w = (int)nwin - 1; w >= 0; --w) {
@@ -212,6 +355,12 @@ template <class Cv>
 static int32_t msm_dev_xyzz(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, typename FastHost<Cv>::G::X* out) {
     if (off > pts->n || n > pts->n - off) return fail(DVN_ERR_INVALID_ARG, "len(points) != len(scalars): range [%zu, %zu) outside point set of %zu", off, off + n, pts->n);
     if (n == 0) { *out = FastHost<Cv>::G::infinity(); return DVN_OK; }
+    if (use_expanded(pts, n)) {
+        std::vector<u32> one((size_t)Cv::XW);
+        TRY(msm_expanded<Cv>(ctx, pts, off, n, (const uint64_t*)d_scalars, DVN_MSM_SCALARS_ON_DEVICE, 0, pts->nexp, one.data()));
+        *out = FastHost<Cv>::G::horner(one.data(), 1, 0);
+        return DVN_OK;
+    }
     u32 c, nwin; msm_plan(n, &c, &nwin);
     std::vector<u32> sums((size_t)nwin * Cv::XW);
     TRY(msm_windows<Cv>(ctx, pts, off, n, (const uint64_t*)d_scalars, DVN_MSM_SCALARS_ON_DEVICE, c, nwin, 0, nwin, sums.data()));
@@ -228,6 +377,12 @@ static int32_t msm_full(dvn_ctx* ctx, const dvn_points* pts, int curve, size_t o
     std::lock_guard<std::mutex> lk(ctx->mu);
     typedef typename FastHost<Cv>::G HG;
     if (n == 0) { HG::write_jac(HG::infinity(), out_jac); ctx->last_ms[0] = ctx->last_ms[1] = 0.f; return DVN_OK; }
+    if (use_expanded(pts, n)) {
+        std::vector<u32> one((size_t)Cv::XW);
+        TRY(msm_expanded<Cv>(ctx, pts, off, n, scalars, flags, 0, pts->nexp, one.data()));
+        HG::write_jac(HG::horner(one.data(), 1, 0), out_jac);      // one bucket set: no window combine left
+        return DVN_OK;
+    }
     u32 c, nwin; msm_plan(n, &c, &nwin);
     std::vector<u32> sums((size_t)nwin * Cv::XW);
     TRY(msm_windows<Cv>(ctx, pts, off, n, scalars, flags, c, nwin, 0, nwin, sums.data()));

@@ -234,6 +234,167 @@ static __global__ void k_scan(const u32* __restrict__ counts, u32* __restrict__ 
     if (t == T - 1) totals[w] = part[t];
 }
 
+// ====================================================================================================================
+// Expanded point sets ("one bucket set").  HBM is 288 GB, a proving key a few GB: at upload the table
+// is widened to rows  row_w[i] = 2^(c w) * P_i,  w < nexp.  Every window of every scalar then lands in the SAME
+// 2^(c-1) buckets, so window size is no longer tied to the bucket-reduction cost: c = 20 gives 13 windows instead of
+// 16 (19 % fewer mixed additions), one bucket reduction instead of 16 and no window combine at all.
+// Sorting 2^19 buckets no longer fits an LDS histogram: two passes -- by the high bits of the bucket (LDS histogram of
+// <= 2048 bins per 64K-entry tile), then one block per high-bits bin sorts its contiguous segment by the low 10 bits.
+// ====================================================================================================================
+constexpr u32 LOB = 10;                       // low bucket bits sorted in pass 2 (2^LOB threads per pass-2 block)
+template <class Cv> __global__ void k_points_expand(u32* __restrict__ table, size_t n, u32 c, u32 nexp) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    typename Cv::A a = ld_affine<Cv>(table + i * Cv::AW);
+    for (u32 w = 1; w < nexp; ++w) {
+        typename Cv::X cur = Cv::from_affine(a);
+        for (u32 k = 0; k < c; ++k) cur = Cv::dbl(cur);
+        a = Cv::to_affine(cur);
+        u32 wds[Cv::AW];
+        Cv::store_affine_internal(a, wds);
+        store_words16(table + ((size_t)w * n + i) * Cv::AW, wds, Cv::AW);
+    }
+}
+// signed c-bit digits (c <= 24) as int32: digits[(w - win_lo) * n + i] in [-2^(c-1), 2^(c-1) - 1]
+static __global__ void k_digits32(const u32* __restrict__ scalars, size_t n, u32 c, u32 win_lo, u32 win_hi, int* __restrict__ digits) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 w[8];
+    load_words16(scalars + i * 8, w, 8);
+    Fr k = fe_ext_mont_to_canonical<FrCfg>(w);
+    u32 kw[9];
+    {
+        u32 t[8]; fe_pack<FrCfg>(k, t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kw[j] = t[j];
+        kw[8] = 0;
+    }
+    const u32 nb = 1u << (c - 1), mask = (1u << c) - 1;
+    u32 carry = 0;
+    for (u32 win = 0; win < win_hi; ++win) {
+        const u32 bit = win * c;
+        u32 d = carry;
+        if (bit < 256) {
+            const u32 wi = bit >> 5, sh = bit & 31;
+            u64 two = (u64)kw[wi] | ((u64)kw[wi + 1] << 32);
+            d += (u32)(two >> sh) & mask;
+        }
+        carry = 0;
+        int v = (int)d;
+        if (d >= nb) { v = (int)d - (int)(1u << c); carry = 1; }
+        if (win >= win_lo) digits[(size_t)(win - win_lo) * n + i] = v;
+    }
+}
+// pass 1, block = tile of the flattened (window, point) entry space: histogram over the high bucket bits
+static __global__ __launch_bounds__(1024) void k_p1_hist(const int* __restrict__ digits, size_t total, u32 tile_len, u32 hb,
+                                                         u32* __restrict__ hist1) {
+    extern __shared__ __align__(16) u32 lh[];
+    for (u32 b = threadIdx.x; b < hb; b += blockDim.x) lh[b] = 0;
+    __syncthreads();
+    const size_t lo = (size_t)blockIdx.x * tile_len, hi = min(lo + (size_t)tile_len, total);
+    for (size_t g = lo + threadIdx.x; g < hi; g += blockDim.x) {
+        const int d = digits[g];
+        if (d) atomicAdd(&lh[((u32)(d < 0 ? -d : d) - 1) >> LOB], 1u);
+    }
+    __syncthreads();
+    for (u32 b = threadIdx.x; b < hb; b += blockDim.x) hist1[(size_t)blockIdx.x * hb + b] = lh[b];
+}
+// block = high bin: exclusive prefix of hist1 over the tiles (in place), bin_total[bin]
+static __global__ __launch_bounds__(1024) void k_p1_offsets(u32* __restrict__ hist1, u32* __restrict__ bin_total, u32 hb, u32 ntiles) {
+    __shared__ u32 part[1024];
+    const u32 bin = blockIdx.x, t = threadIdx.x, T = blockDim.x;
+    const u32 per = (ntiles + T - 1) / T;
+    const u32 lo = t * per, hi = min(lo + per, ntiles);
+    u32 s = 0;
+    for (u32 k = lo; k < hi; ++k) s += hist1[(size_t)k * hb + bin];
+    part[t] = s;
+    __syncthreads();
+    for (u32 d = 1; d < T; d <<= 1) {
+        u32 v = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    u32 run = part[t] - s;
+    for (u32 k = lo; k < hi; ++k) { const u32 v = hist1[(size_t)k * hb + bin]; hist1[(size_t)k * hb + bin] = run; run += v; }
+    if (t == T - 1) bin_total[bin] = part[t];
+}
+// single block: bin_base = exclusive scan of bin_total (hb <= 2048), bin_base[hb] = totals[0] = number of entries
+static __global__ __launch_bounds__(1024) void k_p1_scan(const u32* __restrict__ bin_total, u32* __restrict__ bin_base,
+                                                         u32* __restrict__ totals, u32 hb) {
+    __shared__ u32 part[1024];
+    const u32 t = threadIdx.x, T = blockDim.x;
+    const u32 per = (hb + T - 1) / T;
+    const u32 lo = t * per, hi = min(lo + per, hb);
+    u32 s = 0;
+    for (u32 k = lo; k < hi; ++k) s += bin_total[k];
+    part[t] = s;
+    __syncthreads();
+    for (u32 d = 1; d < T; d <<= 1) {
+        u32 v = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    u32 run = part[t] - s;
+    for (u32 k = lo; k < hi; ++k) { bin_base[k] = run; run += bin_total[k]; }
+    if (t == T - 1) { bin_base[hb] = part[t]; totals[0] = part[t]; }
+}
+// pass 1 scatter: entry (w, i) -> position inside its high bin; carries ref = row * stride + point | sign and the low bits
+static __global__ __launch_bounds__(1024) void k_p1_scatter(const int* __restrict__ digits, size_t total, size_t n, u32 tile_len,
+                                                            u32 hb, u32 win_lo, u32 row_stride, u32 pts_off,
+                                                            const u32* __restrict__ hist1, const u32* __restrict__ bin_base,
+                                                            u32* __restrict__ p1_ref, unsigned short* __restrict__ p1_lo) {
+    extern __shared__ __align__(16) u32 lh[];
+    for (u32 b = threadIdx.x; b < hb; b += blockDim.x) lh[b] = bin_base[b] + hist1[(size_t)blockIdx.x * hb + b];
+    __syncthreads();
+    const size_t lo = (size_t)blockIdx.x * tile_len, hi = min(lo + (size_t)tile_len, total);
+    for (size_t g = lo + threadIdx.x; g < hi; g += blockDim.x) {
+        const int d = digits[g];
+        if (d) {
+            const u32 bucket = (u32)(d < 0 ? -d : d) - 1;
+            const u32 w = (u32)(g / n), i = (u32)(g - (size_t)w * n);
+            const u32 pos = atomicAdd(&lh[bucket >> LOB], 1u);
+            p1_ref[pos] = ((win_lo + w) * row_stride + pts_off + i) | (d < 0 ? SIGN_BIT : 0u);
+            p1_lo[pos] = (unsigned short)(bucket & ((1u << LOB) - 1));
+        }
+    }
+}
+// pass 2, block = high bin: counting sort of the bin's contiguous segment by the low bits; emits the per-bucket
+// counts / offsets the accumulate kernel needs
+static __global__ __launch_bounds__(1024) void k_p2_sort(const u32* __restrict__ bin_base, const u32* __restrict__ p1_ref,
+                                                         const unsigned short* __restrict__ p1_lo, u32* __restrict__ sorted,
+                                                         u32* __restrict__ counts, u32* __restrict__ offsets) {
+    __shared__ u32 cnt[1u << LOB];
+    __shared__ u32 cur[1u << LOB];
+    const u32 bin = blockIdx.x, t = threadIdx.x;           // blockDim.x == 1 << LOB
+    const u32 s0 = bin_base[bin], s1 = bin_base[bin + 1];
+    cnt[t] = 0;
+    __syncthreads();
+    for (u32 e = s0 + t; e < s1; e += blockDim.x) atomicAdd(&cnt[p1_lo[e]], 1u);
+    __syncthreads();
+    const u32 mine = cnt[t];
+    cur[t] = mine;
+    __syncthreads();
+    for (u32 d = 1; d < blockDim.x; d <<= 1) {
+        u32 v = (t >= d) ? cur[t - d] : 0;
+        __syncthreads();
+        cur[t] += v;
+        __syncthreads();
+    }
+    const u32 off = s0 + cur[t] - mine;
+    __syncthreads();
+    cur[t] = off;
+    counts[((size_t)bin << LOB) + t] = mine;
+    offsets[((size_t)bin << LOB) + t] = off;
+    __syncthreads();
+    for (u32 e = s0 + t; e < s1; e += blockDim.x) {
+        const u32 pos = atomicAdd(&cur[p1_lo[e]], 1u);
+        sorted[pos] = p1_ref[e];
+    }
+}
+
 // ---- HOT KERNEL: segment accumulation -------------------------------------------------------------------
 // lane = (window w, segment k): entries [k*seg, min((k+1)*seg, totals[w])) of window w's sorted list.
 template <class Cv>

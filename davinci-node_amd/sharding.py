@@ -38,8 +38,8 @@ def exchange_window_sums(local: np.ndarray, nwin: int, world: int, rank: int, di
 
 def sharded_msm_g1(ctx, pts, scalars, n: int, rank: int, world: int, dist=None, device="cuda") -> np.ndarray:
     """One window-sharded G1 MultiExp; every rank returns the same G1Jac image.  Returns (result, device_ms, kernel_ms)."""
-    c, nwin = ctx.msm_plan(n)
+    _, nwin, combine_bits = ctx.msm_plan_points(pts, n)
     lo, hi = window_slice(nwin, world, rank)
     sums = ctx.msm_g1_windows(pts, scalars, lo, hi, n=n)
     allsums = exchange_window_sums(sums, nwin, world, rank, dist, device)
-    return ctx.msm_combine_g1(allsums, c)
+    return ctx.msm_combine_g1(allsums, combine_bits)

@@ -62,6 +62,10 @@ int32_t dvn_points_upload_g2(dvn_ctx* ctx, const uint64_t* xy_mont, size_t n, dv
  * SplitMix64 stream `seed`.  Bench/test input generator. */
 int32_t dvn_points_synthetic_g1(dvn_ctx* ctx, uint64_t seed, size_t n, dvn_points** out);
 int32_t dvn_points_synthetic_g2(dvn_ctx* ctx, uint64_t seed, size_t n, dvn_points** out);
+/* (Re)build the set as an expanded table for window size window_bits in [11, 24] (row w = 2^(window_bits * w) * P_i,
+ * 254 / window_bits + 1 rows), or collapse it back with 0.  G2 sets of >= 2^17 points are expanded
+ * automatically at upload; G1 sets stay plain by default (measured: no gain). */
+int32_t dvn_points_set_expanded(dvn_ctx* ctx, dvn_points* pts, uint32_t window_bits);
 /* Synthetic scalar vector written to DEVICE memory d_out (n x 4 uint64, gnark Montgomery form): kind 0 =
  * uniform mod r from SplitMix64 stream `seed`, kind 1 = the witness-like mixture of SURVEY.md §8d (40 % zero,
  * 25 % one, 25 % < 2^64, 10 % uniform).  Bench/test input generator. */
@@ -87,6 +91,10 @@ int32_t dvn_msm_g2(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, co
  * (X, Y, ZZ, ZZZ; 16 x uint64 for G1) per window in window_sums; ranks exchange them (RCCL all-gather) and any rank
  * finishes with dvn_msm_combine_g1. */
 int32_t dvn_msm_plan(size_t n, uint32_t* window_bits, uint32_t* nwin);
+/* The plan for THIS point set: large sets are stored as an expanded table (row w = 2^(c w) * P) whose
+ * windows all share one bucket set; then combine_bits = 0 and dvn_msm_g1_windows returns the partial result of the
+ * window range in slot 0 (remaining slots infinity): partial results add up, dvn_msm_combine_g1(.., window_bits = 0). */
+int32_t dvn_msm_plan_points(const dvn_points* pts, size_t n, uint32_t* window_bits, uint32_t* nwin, uint32_t* combine_bits);
 int32_t dvn_msm_g1_windows(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars_mont,
                            uint32_t flags, uint32_t win_lo, uint32_t win_hi, uint64_t* window_sums /* (win_hi-win_lo) x 16 */);
 int32_t dvn_msm_combine_g1(dvn_ctx* ctx, const uint64_t* window_sums /* nwin x 16 */, uint32_t nwin, uint32_t window_bits,

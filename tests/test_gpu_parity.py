@@ -105,11 +105,34 @@ def test_msm_g1_linearity_and_window_sharding(ctx, orc, opy):
     ra, rb, rab = (aff1(orc, ctx.msm_g1(pts, s)) for s in (a, b, ab))
     assert (orc.g1_add(ra, rb) == rab).all()
     # window-sharded evaluation: any split of the windows recombines to the same point
-    c, nwin = ctx.msm_plan(n)
+    _, nwin, cb = ctx.msm_plan_points(pts, n)
     for cuts in ([0, nwin], [0, nwin // 2, nwin], [0, 1, 5, nwin]):
         parts = [ctx.msm_g1_windows(pts, a, lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:])]
-        got = aff1(orc, ctx.msm_combine_g1(np.concatenate(parts), c))
+        got = aff1(orc, ctx.msm_combine_g1(np.concatenate(parts), cb))
         assert (got == ra).all()
+    pts.free()
+    # the same on an EXPANDED point set (one bucket set, partial results add up: combine_bits = 0)
+    n = 1 << 16
+    ph = orc.g1_synthetic_points(32, n)
+    pts = ctx.upload_g1(ph)
+    a = orc.scalars(3, 0, n)
+    want = orc.msm_g1(ph, a)
+    assert ctx.msm_plan_points(pts, n)[2] != 0                      # G1 sets are plain by default
+    pts.set_expanded(18)
+    assert (pts.download(100, 50) == ph[100:150]).all()             # row 0 is untouched
+    cw, nwin, cb = ctx.msm_plan_points(pts, n)
+    assert (cw, nwin, cb) == (18, 15, 0)
+    assert (aff1(orc, ctx.msm_g1(pts, a)) == want).all()
+    for cuts in ([0, nwin], [0, nwin // 2, nwin], [0, 1, 5, nwin]):
+        parts = [ctx.msm_g1_windows(pts, a, lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:])]
+        assert (aff1(orc, ctx.msm_combine_g1(np.concatenate(parts), cb)) == want).all()
+    # a short sub-range of an expanded set falls back to the classic per-window path
+    assert (aff1(orc, ctx.msm_g1(pts, a[:1000], off=77)) == orc.msm_g1(ph[77:1077], a[:1000])).all()
+    assert (aff1(orc, ctx.msm_g1(pts, a[:40000], off=5)) == orc.msm_g1(ph[5:40005], a[:40000])).all()
+    for kind_scalars in (np.repeat(orc.scalars(1, 0, 1), n, axis=0), orc.scalars(9, 1, n)):      # hot bucket / witness-like
+        assert (aff1(orc, ctx.msm_g1(pts, kind_scalars)) == orc.msm_g1(ph, kind_scalars)).all()
+    pts.set_expanded(0)
+    assert (aff1(orc, ctx.msm_g1(pts, a)) == want).all()
     pts.free()
 
 
@@ -145,7 +168,7 @@ def test_msm_g2_golden_vectors(ctx, orc, vectors, conv):
         pts.free()
 
 
-@pytest.mark.parametrize("n", [1, 17, 1000, 1 << 13])
+@pytest.mark.parametrize("n", [1, 17, 1000, 1 << 13, (1 << 17) + 3])          # the last one is an expanded set (c = 18)
 def test_msm_g2_vs_oracle(ctx, orc, n):
     ph = orc.g2_synthetic_points(5, n)
     pts = ctx.upload_g2(ph)
