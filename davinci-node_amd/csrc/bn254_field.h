@@ -202,6 +202,29 @@ template <class C, int K> DVN_HD Fe<C> fe_neg_lazy(const Fe<C>& b) {
     for (int i = 0; i < NL; ++i) r.v[i] = (u32)d[i];
     return r;
 }
+// a + b with one carry pass, no reduction: value a + b, limbs normalised
+template <class C> DVN_HD Fe<C> fe_add_lazy(const Fe<C>& a, const Fe<C>& b) {
+    i32 d[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) d[i] = (i32)(a.v[i] + b.v[i]);
+    fe_carry<C>(d);
+    Fe<C> r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.v[i] = (u32)d[i];
+    return r;
+}
+// x >= K p ? x - K p : x   (x loose with normalised limbs)
+template <class C, int K> DVN_HD Fe<C> fe_csub(const Fe<C>& x) {
+    i32 d[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) d[i] = (i32)x.v[i] - (i32)fe_kp<C, K>(i);
+    fe_carry<C>(d);
+    const bool neg = d[NL - 1] < 0;
+    Fe<C> r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.v[i] = neg ? x.v[i] : (u32)d[i];
+    return r;
+}
 // a + b without carry propagation: limbs < 2^30; only valid as the subtrahend of fe_sub_lazy or a fe_mul operand
 template <class C> DVN_HD Fe<C> fe_add_nocarry(const Fe<C>& a, const Fe<C>& b) {
     Fe<C> r;

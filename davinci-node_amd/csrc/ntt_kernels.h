@@ -66,9 +66,16 @@ __device__ __forceinline__ Fr ntt_scale_factor(const NttScale& sc, u32 i, u32 lo
     return f;
 }
 
-// stages [sa, sb) of a 2^log_n transform; dit = 0: ascending s (DIF), dit = 1: descending s (DIT)
+// values < 4p (the in-pass invariant) -> canonical -> 8 words
+__device__ __forceinline__ void st_fr4(const Fr& v, u32* __restrict__ p) { st_fr(fe_csub<FrCfg, 2>(v), p); }
+
+// stages [sa, sb) of a 2^log_n transform; dit = 0: ascending s (DIF), dit = 1: descending s (DIT).
+// Two stages per LDS round trip (radix-4 units held in registers); values in LDS are kept below 4p ("loose", limbs
+// normalised), so differences feed the twiddle multiplication after ONE carry pass and sums need one conditional
+// subtraction of 4p -- the multiplication itself tolerates operands up to 13p (bn254_field.h).
 static __global__ __launch_bounds__(512) void k_ntt_pass(u32* __restrict__ data, const u32* __restrict__ tw, u32 log_n,
                                                   u32 sa, u32 sb, int dit, u32 log_i, NttScale sc) {
+    typedef FrCfg C;
     extern __shared__ __align__(16) u32 lds[];
     const u32 K = sb - sa, Lb = log_n - sb, I = 1u << log_i;
     const u32 E = I << K;
@@ -80,12 +87,61 @@ static __global__ __launch_bounds__(512) void k_ntt_pass(u32* __restrict__ data,
         const u32 q = le & (I - 1), D = le >> log_i, sp = sp0 + q;
         const u32 gi = ((sp >> Lb) << (Lb + K)) | (D << Lb) | (sp & inner_mask);
         Fr v = ld_fr(data + (size_t)gi * 8);
-        if (sc.mode && sc.when == 1) v = fe_mul<FrCfg>(v, ntt_scale_factor(sc, gi, log_n));
+        if (sc.mode && sc.when == 1) v = fe_mul<C>(v, ntt_scale_factor(sc, gi, log_n));
         st_fr_weak(v, lds + (size_t)le * 8);
     }
     __syncthreads();
-    // ---- butterflies
-    for (u32 t = 0; t < K; ++t) {
+    // ---- radix-4 rounds: executed stages t and t + 1
+    u32 t = 0;
+    for (; t + 1 < K; t += 2) {
+        // bit positions inside D of the two stages; dlo is the lower one
+        const u32 dlo = dit ? t : (K - 2 - t);
+        const u32 s_first = dit ? (sb - 1 - t) : (sa + t);           // first executed stage
+        const u32 s_second = dit ? (s_first - 1) : (s_first + 1);
+        const u32* tab1 = tw + ((size_t)n - (n >> s_first)) * 8;
+        const u32* tab2 = tw + ((size_t)n - (n >> s_second)) * 8;
+        for (u32 u = threadIdx.x; u < (E >> 2); u += blockDim.x) {
+            const u32 q = u & (I - 1), dq = u >> log_i;
+            const u32 low = dq & ((1u << dlo) - 1);
+            const u32 Db = ((dq >> dlo) << (dlo + 2)) | low;
+            const u32 inner = (sp0 + q) & inner_mask;
+            // x[hi][lo]: hi = bit dlo+1 of D, lo = bit dlo
+            u32* p00 = lds + (size_t)((Db << log_i) | q) * 8;
+            u32* p01 = lds + (size_t)(((Db | (1u << dlo)) << log_i) | q) * 8;
+            u32* p10 = lds + (size_t)(((Db | (2u << dlo)) << log_i) | q) * 8;
+            u32* p11 = lds + (size_t)(((Db | (3u << dlo)) << log_i) | q) * 8;
+            const Fr x00 = ld_fr(p00), x01 = ld_fr(p01), x10 = ld_fr(p10), x11 = ld_fr(p11);
+            if (!dit) {
+                // stage s pairs over the HIGH bit (distance 2 << dlo), twiddle depends on the low bit;
+                // stage s+1 pairs over the LOW bit, one twiddle for the whole unit
+                const Fr wa0 = ld_fr(tab1 + (size_t)((low << Lb) | inner) * 8);
+                const Fr wa1 = ld_fr(tab1 + (size_t)((((1u << dlo) | low) << Lb) | inner) * 8);
+                const Fr wb = ld_fr(tab2 + (size_t)((low << Lb) | inner) * 8);
+                const Fr A0 = fe_csub<C, 4>(fe_add_lazy<C>(x00, x10)), A1 = fe_csub<C, 4>(fe_add_lazy<C>(x01, x11));
+                const Fr B0 = fe_mul<C>(fe_sub_lazy<C, 4>(x00, x10), wa0), B1 = fe_mul<C>(fe_sub_lazy<C, 4>(x01, x11), wa1);
+                st_fr_weak(fe_csub<C, 4>(fe_add_lazy<C>(A0, A1)), p00);
+                st_fr_weak(fe_mul<C>(fe_sub_lazy<C, 4>(A0, A1), wb), p01);
+                st_fr_weak(fe_add_lazy<C>(B0, B1), p10);
+                st_fr_weak(fe_mul<C>(fe_sub_lazy<C, 2>(B0, B1), wb), p11);
+            } else {
+                // stage s1 pairs over the LOW bit, one twiddle; stage s1-1 pairs over the HIGH bit, twiddle depends on the low bit
+                const Fr w1 = ld_fr(tab1 + (size_t)((low << Lb) | inner) * 8);
+                const Fr w20 = ld_fr(tab2 + (size_t)((low << Lb) | inner) * 8);
+                const Fr w21 = ld_fr(tab2 + (size_t)((((1u << dlo) | low) << Lb) | inner) * 8);
+                const Fr t0 = fe_mul<C>(x01, w1), t1 = fe_mul<C>(x11, w1);
+                const Fr a00 = fe_add_lazy<C>(x00, t0), a01 = fe_sub_lazy<C, 2>(x00, t0);     // < 5.1p, < 6p
+                const Fr a10 = fe_add_lazy<C>(x10, t1), a11 = fe_sub_lazy<C, 2>(x10, t1);
+                const Fr u0 = fe_mul<C>(a10, w20), u1 = fe_mul<C>(a11, w21);
+                st_fr_weak(fe_csub<C, 4>(fe_add_lazy<C>(a00, u0)), p00);
+                st_fr_weak(fe_csub<C, 4>(fe_add_lazy<C>(a01, u1)), p01);
+                st_fr_weak(fe_csub<C, 4>(fe_sub_lazy<C, 2>(a00, u0)), p10);
+                st_fr_weak(fe_csub<C, 4>(fe_sub_lazy<C, 2>(a01, u1)), p11);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- odd stage count: one radix-2 round for the last executed stage
+    if (t < K) {
         const u32 s = dit ? (sb - 1 - t) : (sa + t);
         const u32 tl = s - sa;
         const u32 dshift = K - 1 - tl, dist = 1u << dshift;
@@ -100,12 +156,12 @@ static __global__ __launch_bounds__(512) void k_ntt_pass(u32* __restrict__ data,
             u32* pb = lds + (size_t)((D1 << log_i) | q) * 8;
             const Fr a = ld_fr(pa), b = ld_fr(pb);
             if (!dit) {
-                st_fr_weak(fe_add<FrCfg>(a, b), pa);
-                st_fr_weak(fe_mul<FrCfg>(fe_sub<FrCfg>(a, b), w), pb);
+                st_fr_weak(fe_csub<C, 4>(fe_add_lazy<C>(a, b)), pa);
+                st_fr_weak(fe_mul<C>(fe_sub_lazy<C, 4>(a, b), w), pb);
             } else {
-                const Fr bt = fe_mul<FrCfg>(b, w);
-                st_fr_weak(fe_add<FrCfg>(a, bt), pa);
-                st_fr_weak(fe_sub<FrCfg>(a, bt), pb);
+                const Fr bt = fe_mul<C>(b, w);
+                st_fr_weak(fe_csub<C, 4>(fe_add_lazy<C>(a, bt)), pa);
+                st_fr_weak(fe_csub<C, 4>(fe_sub_lazy<C, 2>(a, bt)), pb);
             }
         }
         __syncthreads();
@@ -115,8 +171,8 @@ static __global__ __launch_bounds__(512) void k_ntt_pass(u32* __restrict__ data,
         const u32 q = le & (I - 1), D = le >> log_i, sp = sp0 + q;
         const u32 gi = ((sp >> Lb) << (Lb + K)) | (D << Lb) | (sp & inner_mask);
         Fr v = ld_fr(lds + (size_t)le * 8);
-        if (sc.mode && sc.when == 2) v = fe_mul<FrCfg>(v, ntt_scale_factor(sc, gi, log_n));
-        st_fr(v, data + (size_t)gi * 8);
+        if (sc.mode && sc.when == 2) st_fr(fe_mul<C>(v, ntt_scale_factor(sc, gi, log_n)), data + (size_t)gi * 8);
+        else st_fr4(v, data + (size_t)gi * 8);
     }
 }
 
