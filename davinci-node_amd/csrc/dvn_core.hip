@@ -33,6 +33,13 @@ extern "C" int32_t dvn_init(const int* devs, int ndev, dvn_ctx** out) {
     hipError_t e2 = hipSetDevice(dev);
     if (e2 == hipSuccess) e2 = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e2 == hipSuccess; ++i) e2 = hipEventCreate(&ctx->ev[i]);
+    if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&ctx->ev_dep, hipEventDisableTiming);
+    for (int l = 0; l < DVN_LANES && e2 == hipSuccess; ++l) {
+        MsmLane& L = ctx->lane[l];
+        e2 = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking);
+        for (int i = 0; i < 4 && e2 == hipSuccess; ++i) e2 = hipEventCreate(&L.ev[i]);
+        if (e2 == hipSuccess) e2 = hipHostMalloc((void**)&L.h_sums, DVN_HSUMS_WORDS * 4, hipHostMallocDefault);
+    }
     if (e2 != hipSuccess) { delete ctx; (void)hipGetLastError(); return fail(DVN_ERR_DEVICE, "context setup failed: %s", hipGetErrorString(e2)); }
     *out = ctx;
     return DVN_OK;
@@ -42,6 +49,15 @@ extern "C" void dvn_shutdown(dvn_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    for (int l = 0; l < DVN_LANES; ++l) {
+        MsmLane& L = ctx->lane[l];
+        if (L.stream) (void)hipStreamSynchronize(L.stream);
+        if (L.ws) (void)hipFree(L.ws);
+        if (L.h_sums) (void)hipHostFree(L.h_sums);
+        for (int i = 0; i < 4; ++i) if (L.ev[i]) (void)hipEventDestroy(L.ev[i]);
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+    }
+    if (ctx->ev_dep) (void)hipEventDestroy(ctx->ev_dep);
     for (int i = 0; i < 4; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

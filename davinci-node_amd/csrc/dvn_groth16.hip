@@ -420,11 +420,19 @@ extern "C" int32_t dvn_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uin
         typedef dvn_host::HG1 H1;
         typedef dvn_host::HG2 H2;
         H1::X mA, mB, mK, mZ; H2::X mB2;
-        TRY(dvn_internal_msm_g1_dev(ctx, pk->A, 0, pk->nA, pk->d_wA, &mA));
-        TRY(dvn_internal_msm_g1_dev(ctx, pk->B, 0, pk->nB, pk->d_wB, &mB));
-        TRY(dvn_internal_msm_g2_dev(ctx, pk->B2, 0, pk->nB, pk->d_wB, &mB2));
-        TRY(dvn_internal_msm_g1_dev(ctx, pk->K, 0, m - pk->n_public, pk->d_w + pk->n_public * 8, &mK));
-        TRY(dvn_internal_msm_g1_dev(ctx, pk->Z, 0, n - 1, pk->d_abc, &mZ));              // h[:n-1] against Z[:n-1]
+        // two MSMs in flight: the sort and the latency-bound tail of one run under the accumulate kernel of the other;
+        // the G2 MSM (the longest) goes first and stays in flight while the G1 ones cycle through the second lane
+        MsmLane *l2 = nullptr, *l1 = nullptr;
+        TRY(dvn_internal_msm_submit_g2(ctx, pk->B2, 0, pk->nB, pk->d_wB, &l2));
+        TRY(dvn_internal_msm_submit_g1(ctx, pk->A, 0, pk->nA, pk->d_wA, &l1));
+        TRY(dvn_internal_msm_collect_g1(ctx, l1, &mA));
+        TRY(dvn_internal_msm_submit_g1(ctx, pk->B, 0, pk->nB, pk->d_wB, &l1));
+        TRY(dvn_internal_msm_collect_g1(ctx, l1, &mB));
+        TRY(dvn_internal_msm_submit_g1(ctx, pk->K, 0, m - pk->n_public, pk->d_w + pk->n_public * 8, &l1));
+        TRY(dvn_internal_msm_collect_g1(ctx, l1, &mK));
+        TRY(dvn_internal_msm_submit_g1(ctx, pk->Z, 0, n - 1, pk->d_abc, &l1));               // h[:n-1] against Z[:n-1]
+        TRY(dvn_internal_msm_collect_g1(ctx, l1, &mZ));
+        TRY(dvn_internal_msm_collect_g2(ctx, l2, &mB2));
         HIP_TRY(hipEventRecord(e2, st));
         HIP_TRY(hipStreamSynchronize(st));
         // (5)(7) blinding and assembly on the host: O(1) group operations (host_fast.h)

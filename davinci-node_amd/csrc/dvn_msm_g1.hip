@@ -7,6 +7,10 @@ extern "C" int32_t dvn_points_upload_g1(dvn_ctx* ctx, const uint64_t* xy, size_t
 
 extern "C" int32_t dvn_points_synthetic_g1(dvn_ctx* ctx, uint64_t seed, size_t n, dvn_points** out) { return points_synthetic<G1>(ctx, seed, n, 1, g1_generator(), out); }
 
+extern "C" int32_t dvn_msm_g1_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags, int32_t* ticket) {
+    return msm_submit_api<G1>(ctx, pts, 1, off, n, scalars, flags, ticket);
+}
+extern "C" int32_t dvn_msm_g1_collect(dvn_ctx* ctx, int32_t ticket, uint64_t out_jac[12]) { return msm_collect_api<G1>(ctx, 1, ticket, out_jac); }
 extern "C" int32_t dvn_msm_g1(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags, uint64_t out_jac[12]) {
     return msm_full<G1>(ctx, pts, 1, off, n, scalars, flags, out_jac);
 }
@@ -35,8 +39,13 @@ extern "C" int32_t dvn_msm_g1_windows(dvn_ctx* ctx, const dvn_points* pts, size_
     std::lock_guard<std::mutex> lk(ctx->mu);
     std::vector<u32> sums((size_t)W * G1::XW, 0u);
     if (n) {
-        if (expanded) TRY(msm_expanded<G1>(ctx, pts, off, n, scalars, flags, win_lo, win_hi, sums.data()));   // slot 0 = partial sum
-        else TRY(msm_windows<G1>(ctx, pts, off, n, scalars, flags, c, nwin, win_lo, win_hi, sums.data()));
+        MsmLane* L = nullptr;
+        TRY(lane_acquire(ctx, &L));
+        int32_t rc = expanded ? msm_expanded<G1>(ctx, *L, pts, off, n, scalars, flags, win_lo, win_hi)    // slot 0 = partial sum
+                              : msm_windows<G1>(ctx, *L, pts, off, n, scalars, flags, c, nwin, win_lo, win_hi);
+        if (rc != DVN_OK) { (void)hipStreamSynchronize(L->stream); L->busy = false; return rc; }
+        TRY(lane_wait(ctx, *L));
+        memcpy(sums.data(), L->h_sums, (size_t)(expanded ? 1 : W) * G1::XW * 4);
     }
     // export as external-Montgomery (X, Y, ZZ, ZZZ); infinity = all zero
     u32* o = (u32*)window_sums;
@@ -114,3 +123,9 @@ int32_t dvn_internal_msm_g1_dev(dvn_ctx* ctx, const dvn_points* pts, size_t off,
     if (pts->curve != 1) return fail(DVN_ERR_INVALID_ARG, "point set is not G1");
     return msm_dev_xyzz<G1>(ctx, pts, off, n, d_scalars, out);
 }
+
+int32_t dvn_internal_msm_submit_g1(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, MsmLane** lane) {
+    if (pts->curve != 1) return fail(DVN_ERR_INVALID_ARG, "point set is not G1");
+    return msm_submit<G1>(ctx, pts, off, n, (const uint64_t*)d_scalars, DVN_MSM_SCALARS_ON_DEVICE, lane);
+}
+int32_t dvn_internal_msm_collect_g1(dvn_ctx* ctx, MsmLane* lane, dvn_host::HG1::X* out) { return msm_collect<G1>(ctx, *lane, out); }

@@ -5,6 +5,10 @@ extern "C" int32_t dvn_points_upload_g2(dvn_ctx* ctx, const uint64_t* xy, size_t
 
 extern "C" int32_t dvn_points_synthetic_g2(dvn_ctx* ctx, uint64_t seed, size_t n, dvn_points** out) { return points_synthetic<G2>(ctx, seed, n, 2, g2_generator(), out); }
 
+extern "C" int32_t dvn_msm_g2_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags, int32_t* ticket) {
+    return msm_submit_api<G2>(ctx, pts, 2, off, n, scalars, flags, ticket);
+}
+extern "C" int32_t dvn_msm_g2_collect(dvn_ctx* ctx, int32_t ticket, uint64_t out_jac[24]) { return msm_collect_api<G2>(ctx, 2, ticket, out_jac); }
 extern "C" int32_t dvn_msm_g2(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags, uint64_t out_jac[24]) {
     return msm_full<G2>(ctx, pts, 2, off, n, scalars, flags, out_jac);
 }
@@ -19,3 +23,9 @@ int32_t dvn_internal_msm_g2_dev(dvn_ctx* ctx, const dvn_points* pts, size_t off,
 }
 
 int32_t dvn_internal_points_set_expanded_g2(dvn_ctx* ctx, dvn_points* pts, u32 c) { return points_set_expanded<G2>(ctx, pts, c); }
+
+int32_t dvn_internal_msm_submit_g2(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, MsmLane** lane) {
+    if (pts->curve != 2) return fail(DVN_ERR_INVALID_ARG, "point set is not G2");
+    return msm_submit<G2>(ctx, pts, off, n, (const uint64_t*)d_scalars, DVN_MSM_SCALARS_ON_DEVICE, lane);
+}
+int32_t dvn_internal_msm_collect_g2(dvn_ctx* ctx, MsmLane* lane, dvn_host::HG2::X* out) { return msm_collect<G2>(ctx, *lane, out); }

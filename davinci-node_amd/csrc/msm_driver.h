@@ -112,15 +112,17 @@ template <class Cv> static u32 pick_segment(size_t total) {
 }
 
 // window sums for windows [win_lo, win_hi) -> host, internal packed xyzz images (XW words each)
+// ENQUEUE only: the kernels and the D2H copy of the window sums (into L.h_sums) are queued on the lane's stream;
+// lane_wait() completes them.
 template <class Cv>
-static int32_t msm_windows(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
-                           u32 c, u32 nwin, u32 win_lo, u32 win_hi, u32* host_sums) {
+static int32_t msm_windows(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
+                           u32 c, u32 nwin, u32 win_lo, u32 win_hi) {
     const u32 W = win_hi - win_lo;
     const u32 nb = 1u << (c - 1);
     const u32 seg = pick_segment<Cv>((size_t)n * W);
     const u32 nseg = (u32)((n + seg - 1) / seg);
-    const u32 L = 8;                                               // buckets per thread in the reduction (latency-bound: keep chains short)
-    const u32 bpw = (nb + 256 * L - 1) / (256 * L);                // reduction blocks per window
+    const u32 LB8 = 8;                                             // buckets per thread in the reduction (latency-bound: keep chains short)
+    const u32 bpw = (nb + 256 * LB8 - 1) / (256 * LB8);                // reduction blocks per window
     const u32 heavy_cap = (u32)(((size_t)W * nseg) / (FIX_LIGHT - 1) + 1);
     const bool on_dev = flags & DVN_MSM_SCALARS_ON_DEVICE;
 
@@ -135,12 +137,12 @@ static int32_t msm_windows(dvn_ctx* ctx, const dvn_points* pts, size_t off, size
     cs.take((size_t)W * nb * Cv::XW * 4);                             // bucket sums
     cs.take((size_t)W * nseg * Cv::XW * 4); cs.take((size_t)W * nseg * Cv::XW * 4);   // edges
     cs.take((size_t)W * bpw * Cv::XW * 4); cs.take((size_t)W * Cv::XW * 4);
-    TRY(ensure_ws(ctx, cs.off + 8192));
-    Carver cv(ctx->ws);
+    TRY(lane_ensure_ws(L, cs.off + 8192));
+    Carver cv(L.ws);
     const u32* d_scalars;
     if (!on_dev) {
         u32* tmp = cv.take<u32>(n * 8);
-        HIP_TRY(hipMemcpyAsync(tmp, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpy(tmp, scalars, n * 32, hipMemcpyHostToDevice));   // caller's buffer is free on return (cgo rule)
         d_scalars = tmp;
     } else d_scalars = (const u32*)scalars;
     int16_t* digits = cv.take<int16_t>((size_t)W * n);
@@ -157,7 +159,7 @@ static int32_t msm_windows(dvn_ctx* ctx, const dvn_points* pts, size_t off, size
     u32* partials = cv.take<u32>((size_t)W * bpw * Cv::XW);
     u32* wsums = cv.take<u32>((size_t)W * Cv::XW);
 
-    hipStream_t st = ctx->stream;
+    hipStream_t st = L.stream;
     static const bool dbg = getenv("DVN_DEBUG_SYNC") != nullptr;
 #define DBG_SYNC(name) do { if (dbg) { hipError_t _e = hipStreamSynchronize(st); fprintf(stderr, "[dvn] %s: %s\n", name, hipGetErrorString(_e)); fflush(stderr); if (_e != hipSuccess) return fail(DVN_ERR_DEVICE, "%s: %s", name, hipGetErrorString(_e)); } } while (0)
     if (dbg) { fprintf(stderr, "[dvn] msm n=%zu c=%u W=%u nb=%u seg=%u nseg=%u bpw=%u ntiles=%u ws=%zu\n", n, c, W, nb, seg, nseg, bpw, ntiles, cs.off); fflush(stderr); }
@@ -168,7 +170,7 @@ static int32_t msm_windows(dvn_ctx* ctx, const dvn_points* pts, size_t off, size
         HIP_TRY(hipFuncSetAttribute((const void*)k_tile_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         lds_attr_set = true;
     }
-    HIP_TRY(hipEventRecord(ctx->ev[0], st));
+    HIP_TRY(hipEventRecord(L.ev[0], st));
     HIP_TRY(hipMemsetAsync(totals, 0, (size_t)(W + 1) * 4, st));
     k_digits16<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_scalars, n, c, win_lo, win_hi, digits);
     DBG_SYNC("k_digits16");
@@ -180,27 +182,25 @@ static int32_t msm_windows(dvn_ctx* ctx, const dvn_points* pts, size_t off, size
     DBG_SYNC("k_scan");
     k_tile_scatter<<<W * ntiles, 1024, hist_lds, st>>>(digits, n, nb, tile_len, ntiles, hist, offsets, sorted);
     DBG_SYNC("k_tile_scatter");
-    HIP_TRY(hipEventRecord(ctx->ev[2], st));
+    HIP_TRY(hipEventRecord(L.ev[2], st));
     k_accumulate<Cv><<<(unsigned)(((size_t)W * nseg + 127) / 128), 128, 0, st>>>(pts->d, off, sorted, offsets, counts, totals, buckets,
                                                                               edge_first, edge_last, n, nb, seg, nseg, W);
     DBG_SYNC("k_accumulate");
-    HIP_TRY(hipEventRecord(ctx->ev[3], st));
+    HIP_TRY(hipEventRecord(L.ev[3], st));
     k_fix<Cv><<<(unsigned)(((size_t)W * nb + 127) / 128), 128, 0, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list,
                                                                      heavy_count, W, nb, seg, nseg, heavy_cap);
     DBG_SYNC("k_fix");
     const size_t sh_bytes = (size_t)256 * Cv::XW * 4;
     k_fix_heavy<Cv><<<512, 256, sh_bytes, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list, heavy_count, nb, seg, nseg, heavy_cap);
     DBG_SYNC("k_fix_heavy");
-    k_bucket_reduce<Cv><<<W * bpw, 256, sh_bytes, st>>>(buckets, partials, nb, L, bpw);
+    k_bucket_reduce<Cv><<<W * bpw, 256, sh_bytes, st>>>(buckets, partials, nb, LB8, bpw);
     DBG_SYNC("k_bucket_reduce");
     k_window_finalize<Cv><<<W, 64, (size_t)64 * Cv::XW * 4, st>>>(partials, wsums, W, bpw);
     DBG_SYNC("k_window_finalize");
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ctx->ev[1], st));
-    HIP_TRY(hipMemcpyAsync(host_sums, wsums, (size_t)W * Cv::XW * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipEventElapsedTime(&ctx->last_ms[0], ctx->ev[0], ctx->ev[1]));
-    HIP_TRY(hipEventElapsedTime(&ctx->last_ms[1], ctx->ev[2], ctx->ev[3]));
+    HIP_TRY(hipEventRecord(L.ev[1], st));
+    if ((size_t)W * Cv::XW > DVN_HSUMS_WORDS) return fail(DVN_ERR_INVALID_ARG, "too many windows for the result buffer");
+    HIP_TRY(hipMemcpyAsync(L.h_sums, wsums, (size_t)W * Cv::XW * 4, hipMemcpyDeviceToHost, st));
     return DVN_OK;
 }
 
@@ -213,16 +213,16 @@ static inline bool use_expanded(const dvn_points* pts, size_t n) {
     return pts->expand_c != 0 && n >= ((size_t)1 << 15) && n * 4 >= pts->n;
 }
 template <class Cv>
-static int32_t msm_expanded(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
-                            u32 win_lo, u32 win_hi, u32* host_sum) {
+static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
+                            u32 win_lo, u32 win_hi) {
     const u32 c = pts->expand_c, W = win_hi - win_lo;
     const u32 nb = 1u << (c - 1), hb = nb >> LOB;
     const size_t total = (size_t)W * n;                              // upper bound on the number of entries
     if (total >= ((size_t)1 << 31) || (size_t)pts->nexp * pts->n >= ((size_t)1 << 31)) return fail(DVN_ERR_INVALID_ARG, "MSM too large for 31-bit entry references");
     const u32 seg = pick_segment<Cv>(total);
     const u32 nseg = (u32)((total + seg - 1) / seg);
-    const u32 L = 8;
-    const u32 bpw = (nb + 256 * L - 1) / (256 * L);
+    const u32 LB8 = 8;
+    const u32 bpw = (nb + 256 * LB8 - 1) / (256 * LB8);
     const u32 heavy_cap = (u32)(nseg / (FIX_LIGHT - 1) + 1);
     const u32 tile_len = 65536;
     const u32 ntiles = (u32)((total + tile_len - 1) / tile_len);
@@ -237,12 +237,12 @@ static int32_t msm_expanded(dvn_ctx* ctx, const dvn_points* pts, size_t off, siz
     cs.take((size_t)nb * Cv::XW * 4);
     cs.take((size_t)nseg * Cv::XW * 4); cs.take((size_t)nseg * Cv::XW * 4);
     cs.take((size_t)bpw * Cv::XW * 4); cs.take((size_t)Cv::XW * 4);
-    TRY(ensure_ws(ctx, cs.off + 8192));
-    Carver cv(ctx->ws);
+    TRY(lane_ensure_ws(L, cs.off + 8192));
+    Carver cv(L.ws);
     const u32* d_scalars;
     if (!on_dev) {
         u32* tmp = cv.take<u32>(n * 8);
-        HIP_TRY(hipMemcpyAsync(tmp, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpy(tmp, scalars, n * 32, hipMemcpyHostToDevice));   // caller's buffer is free on return (cgo rule)
         d_scalars = tmp;
     } else d_scalars = (const u32*)scalars;
     int* digits = cv.take<int>(total);
@@ -263,10 +263,10 @@ static int32_t msm_expanded(dvn_ctx* ctx, const dvn_points* pts, size_t off, siz
     u32* partials = cv.take<u32>((size_t)bpw * Cv::XW);
     u32* wsum = cv.take<u32>(Cv::XW);
 
-    hipStream_t st = ctx->stream;
+    hipStream_t st = L.stream;
     static const bool dbg = getenv("DVN_DEBUG_SYNC") != nullptr;
     if (dbg) { fprintf(stderr, "[dvn] msm(expanded) n=%zu c=%u W=%u nb=%u hb=%u seg=%u nseg=%u ntiles=%u ws=%zu\n", n, c, W, nb, hb, seg, nseg, ntiles, cs.off); fflush(stderr); }
-    HIP_TRY(hipEventRecord(ctx->ev[0], st));
+    HIP_TRY(hipEventRecord(L.ev[0], st));
     HIP_TRY(hipMemsetAsync(totals, 0, 16, st));
     k_digits32<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_scalars, n, c, win_lo, win_hi, digits);
     DBG_SYNC("k_digits32");
@@ -280,27 +280,24 @@ static int32_t msm_expanded(dvn_ctx* ctx, const dvn_points* pts, size_t off, siz
     DBG_SYNC("k_p1_scatter");
     k_p2_sort<<<hb, 1u << LOB, 0, st>>>(bin_base, p1_ref, p1_lo, sorted, counts, offsets);
     DBG_SYNC("k_p2_sort");
-    HIP_TRY(hipEventRecord(ctx->ev[2], st));
+    HIP_TRY(hipEventRecord(L.ev[2], st));
     k_accumulate<Cv><<<(unsigned)(((size_t)nseg + 127) / 128), 128, 0, st>>>(pts->d, 0, sorted, offsets, counts, totals, buckets,
                                                                           edge_first, edge_last, total, nb, seg, nseg, 1);
     DBG_SYNC("k_accumulate");
-    HIP_TRY(hipEventRecord(ctx->ev[3], st));
+    HIP_TRY(hipEventRecord(L.ev[3], st));
     k_fix<Cv><<<(unsigned)(((size_t)nb + 127) / 128), 128, 0, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list,
                                                                  heavy_count, 1, nb, seg, nseg, heavy_cap);
     DBG_SYNC("k_fix");
     const size_t sh_bytes = (size_t)256 * Cv::XW * 4;
     k_fix_heavy<Cv><<<512, 256, sh_bytes, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list, heavy_count, nb, seg, nseg, heavy_cap);
     DBG_SYNC("k_fix_heavy");
-    k_bucket_reduce<Cv><<<bpw, 256, sh_bytes, st>>>(buckets, partials, nb, L, bpw);
+    k_bucket_reduce<Cv><<<bpw, 256, sh_bytes, st>>>(buckets, partials, nb, LB8, bpw);
     DBG_SYNC("k_bucket_reduce");
     k_window_finalize<Cv><<<1, 64, (size_t)64 * Cv::XW * 4, st>>>(partials, wsum, 1, bpw);
     DBG_SYNC("k_window_finalize");
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ctx->ev[1], st));
-    HIP_TRY(hipMemcpyAsync(host_sum, wsum, (size_t)Cv::XW * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipEventElapsedTime(&ctx->last_ms[0], ctx->ev[0], ctx->ev[1]));
-    HIP_TRY(hipEventElapsedTime(&ctx->last_ms[1], ctx->ev[2], ctx->ev[3]));
+    HIP_TRY(hipEventRecord(L.ev[1], st));
+    HIP_TRY(hipMemcpyAsync(L.h_sums, wsum, (size_t)Cv::XW * 4, hipMemcpyDeviceToHost, st));
     return DVN_OK;
 }
 
@@ -350,22 +347,67 @@ template <class Cv> struct FastHost;
 template <> struct FastHost<G1> { typedef dvn_host::HG1 G; };
 template <> struct FastHost<G2> { typedef dvn_host::HG2 G; };
 
+// ---- lanes: submit (enqueue on a free lane) / wait --------------------------------------------------------------
+static inline int32_t lane_acquire(dvn_ctx* ctx, MsmLane** out) {
+    for (int k = 0; k < DVN_LANES; ++k) {
+        MsmLane& L = ctx->lane[k];
+        if (!L.busy) {
+            // work queued earlier on the context's main stream (gathers, computeH, uploads) must be visible to this lane
+            HIP_TRY(hipEventRecord(ctx->ev_dep, ctx->stream));
+            HIP_TRY(hipStreamWaitEvent(L.stream, ctx->ev_dep, 0));
+            L.busy = true; L.seq++;
+            *out = &L;
+            return DVN_OK;
+        }
+    }
+    return fail(DVN_ERR_INVALID_ARG, "too many MSMs in flight (collect one of the %d outstanding tickets first)", DVN_LANES);
+}
+static inline int32_t lane_wait(dvn_ctx* ctx, MsmLane& L) {
+    hipError_t e = hipStreamSynchronize(L.stream);
+    L.busy = false;
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(DVN_ERR_DEVICE, "MSM failed on the device: %s", hipGetErrorString(e)); }
+    HIP_TRY(hipEventElapsedTime(&L.ms[0], L.ev[0], L.ev[1]));
+    HIP_TRY(hipEventElapsedTime(&L.ms[1], L.ev[2], L.ev[3]));
+    ctx->last_ms[0] = L.ms[0]; ctx->last_ms[1] = L.ms[1];
+    return DVN_OK;
+}
+// queue a full MSM (all windows) on a free lane; *lane_out identifies it
+template <class Cv>
+static int32_t msm_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags, MsmLane** lane_out) {
+    if (off > pts->n || n > pts->n - off) return fail(DVN_ERR_INVALID_ARG, "len(points) != len(scalars): range [%zu, %zu) outside point set of %zu", off, off + n, pts->n);
+    MsmLane* L = nullptr;
+    TRY(lane_acquire(ctx, &L));
+    L->curve = pts->curve; L->W = 0;
+    int32_t rc = DVN_OK;
+    if (n == 0) { L->nwin = 0; }
+    else if (use_expanded(pts, n)) {
+        L->expanded = true; L->c = 0; L->nwin = 1;
+        rc = msm_expanded<Cv>(ctx, *L, pts, off, n, scalars, flags, 0, pts->nexp);
+    } else {
+        u32 c, nwin; msm_plan(n, &c, &nwin);
+        L->expanded = false; L->c = c; L->nwin = nwin;
+        rc = msm_windows<Cv>(ctx, *L, pts, off, n, scalars, flags, c, nwin, 0, nwin);
+    }
+    if (rc != DVN_OK) { (void)hipStreamSynchronize(L->stream); L->busy = false; return rc; }
+    *lane_out = L;
+    return DVN_OK;
+}
+// complete it: host-side window combine (host_fast.h)
+template <class Cv>
+static int32_t msm_collect(dvn_ctx* ctx, MsmLane& L, typename FastHost<Cv>::G::X* out) {
+    typedef typename FastHost<Cv>::G HG;
+    if (L.nwin == 0) { L.busy = false; *out = HG::infinity(); ctx->last_ms[0] = ctx->last_ms[1] = 0.f; return DVN_OK; }
+    TRY(lane_wait(ctx, L));
+    *out = HG::horner(L.h_sums, L.nwin, L.c);
+    return DVN_OK;
+}
+
 // device scalars -> host (4x64-limb) extended-Jacobian point (caller holds the lock)
 template <class Cv>
 static int32_t msm_dev_xyzz(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, typename FastHost<Cv>::G::X* out) {
-    if (off > pts->n || n > pts->n - off) return fail(DVN_ERR_INVALID_ARG, "len(points) != len(scalars): range [%zu, %zu) outside point set of %zu", off, off + n, pts->n);
-    if (n == 0) { *out = FastHost<Cv>::G::infinity(); return DVN_OK; }
-    if (use_expanded(pts, n)) {
-        std::vector<u32> one((size_t)Cv::XW);
-        TRY(msm_expanded<Cv>(ctx, pts, off, n, (const uint64_t*)d_scalars, DVN_MSM_SCALARS_ON_DEVICE, 0, pts->nexp, one.data()));
-        *out = FastHost<Cv>::G::horner(one.data(), 1, 0);
-        return DVN_OK;
-    }
-    u32 c, nwin; msm_plan(n, &c, &nwin);
-    std::vector<u32> sums((size_t)nwin * Cv::XW);
-    TRY(msm_windows<Cv>(ctx, pts, off, n, (const uint64_t*)d_scalars, DVN_MSM_SCALARS_ON_DEVICE, c, nwin, 0, nwin, sums.data()));
-    *out = FastHost<Cv>::G::horner(sums.data(), nwin, c);
-    return DVN_OK;
+    MsmLane* L = nullptr;
+    TRY(msm_submit<Cv>(ctx, pts, off, n, (const uint64_t*)d_scalars, DVN_MSM_SCALARS_ON_DEVICE, &L));
+    return msm_collect<Cv>(ctx, *L, out);
 }
 
 template <class Cv>
@@ -373,20 +415,37 @@ static int32_t msm_full(dvn_ctx* ctx, const dvn_points* pts, int curve, size_t o
     TRY(enter(ctx));
     if (!pts || !out_jac || (!scalars && n)) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (pts->curve != curve) return fail(DVN_ERR_INVALID_ARG, "point set is G%d, call is G%d", pts->curve, curve);
-    if (off > pts->n || n > pts->n - off) return fail(DVN_ERR_INVALID_ARG, "len(points) != len(scalars): range [%zu, %zu) outside point set of %zu", off, off + n, pts->n);
-    std::lock_guard<std::mutex> lk(ctx->mu);
     typedef typename FastHost<Cv>::G HG;
-    if (n == 0) { HG::write_jac(HG::infinity(), out_jac); ctx->last_ms[0] = ctx->last_ms[1] = 0.f; return DVN_OK; }
-    if (use_expanded(pts, n)) {
-        std::vector<u32> one((size_t)Cv::XW);
-        TRY(msm_expanded<Cv>(ctx, pts, off, n, scalars, flags, 0, pts->nexp, one.data()));
-        HG::write_jac(HG::horner(one.data(), 1, 0), out_jac);      // one bucket set: no window combine left
-        return DVN_OK;
-    }
-    u32 c, nwin; msm_plan(n, &c, &nwin);
-    std::vector<u32> sums((size_t)nwin * Cv::XW);
-    TRY(msm_windows<Cv>(ctx, pts, off, n, scalars, flags, c, nwin, 0, nwin, sums.data()));
-    HG::write_jac(HG::horner(sums.data(), nwin, c), out_jac);     // MSB-first window combine on the host (host_fast.h)
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    MsmLane* L = nullptr;
+    TRY(msm_submit<Cv>(ctx, pts, off, n, scalars, flags, &L));
+    typename HG::X r;
+    TRY(msm_collect<Cv>(ctx, *L, &r));
+    HG::write_jac(r, out_jac);      // MSB-first window combine happened on the host (host_fast.h)
     return DVN_OK;
 }
-
+// asynchronous pair: submit returns a ticket (lane index + 1), collect finishes that MSM
+template <class Cv>
+static int32_t msm_submit_api(dvn_ctx* ctx, const dvn_points* pts, int curve, size_t off, size_t n, const uint64_t* scalars, uint32_t flags, int32_t* ticket) {
+    TRY(enter(ctx));
+    if (!pts || !ticket || (!scalars && n)) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    if (pts->curve != curve) return fail(DVN_ERR_INVALID_ARG, "point set is G%d, call is G%d", pts->curve, curve);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    MsmLane* L = nullptr;
+    TRY(msm_submit<Cv>(ctx, pts, off, n, scalars, flags, &L));
+    *ticket = (int32_t)(L - ctx->lane) + 1;
+    return DVN_OK;
+}
+template <class Cv>
+static int32_t msm_collect_api(dvn_ctx* ctx, int curve, int32_t ticket, uint64_t* out_jac) {
+    TRY(enter(ctx));
+    if (!out_jac || ticket < 1 || ticket > DVN_LANES) return fail(DVN_ERR_INVALID_ARG, "bad ticket");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    MsmLane& L = ctx->lane[ticket - 1];
+    if (!L.busy || L.curve != curve) return fail(DVN_ERR_INVALID_ARG, "ticket %d is not an outstanding G%d MSM", ticket, curve);
+    typedef typename FastHost<Cv>::G HG;
+    typename HG::X r;
+    TRY(msm_collect<Cv>(ctx, L, &r));
+    HG::write_jac(r, out_jac);
+    return DVN_OK;
+}

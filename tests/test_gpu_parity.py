@@ -159,6 +159,33 @@ def test_msm_g1_full_size_closed_form(ctx, orc, opy, log_n):
     pts.free()
 
 
+def test_msm_async_two_in_flight(ctx, orc, pkg):
+    """submit/collect: two MSMs in flight on the two lanes, results identical to the synchronous call; a third submit
+    is refused until a ticket is collected."""
+    n = 20000
+    ph = orc.g1_synthetic_points(41, n); pts = ctx.upload_g1(ph)
+    a, b = orc.scalars(1, 0, n), orc.scalars(2, 1, n)
+    da, db = ctx.to_device(a), ctx.to_device(b)
+    for _ in range(3):
+        t1 = ctx.msm_g1_submit(pts, da, n=n)
+        t2 = ctx.msm_g1_submit(pts, db, n=n)
+        assert {t1, t2} == {1, 2}
+        with pytest.raises(pkg.DvnError):
+            ctx.msm_g1_submit(pts, da, n=n)
+        r2 = ctx.msm_g1_collect(t2); r1 = ctx.msm_g1_collect(t1)
+        assert (aff1(orc, r1) == orc.msm_g1(ph, a)).all() and (aff1(orc, r2) == orc.msm_g1(ph, b)).all()
+    with pytest.raises(pkg.DvnError):
+        ctx.msm_g1_collect(1)                       # nothing outstanding
+    # host scalars may be reused as soon as submit returns
+    h = a.copy(); t1 = ctx.msm_g1_submit(pts, h); h[:] = 0
+    assert (aff1(orc, ctx.msm_g1_collect(t1)) == orc.msm_g1(ph, a)).all()
+    p2h = orc.g2_synthetic_points(3, 500); p2 = ctx.upload_g2(p2h); s2 = orc.scalars(5, 0, 500)
+    t2 = ctx.msm_g2_submit(p2, s2); t1 = ctx.msm_g1_submit(pts, da, n=n)
+    assert (aff1(orc, ctx.msm_g1_collect(t1)) == orc.msm_g1(ph, a)).all()
+    assert (aff2(orc, ctx.msm_g2_collect(t2)) == orc.msm_g2(p2h, s2)).all()
+    ctx.free(da); ctx.free(db); pts.free(); p2.free()
+
+
 # ---- MSM G2 -----------------------------------------------------------------------------------------------------
 def test_msm_g2_golden_vectors(ctx, orc, vectors, conv):
     for case in vectors["msm_g2"]:
