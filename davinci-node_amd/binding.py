@@ -71,6 +71,8 @@ def load_library():
         "dvn_msm_plan": (i32, [sz, C.POINTER(u32), C.POINTER(u32)]),
         "dvn_msm_plan_points": (i32, [vp, sz, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),
         "dvn_msm_g1_windows": (i32, [vp, vp, sz, sz, vp, u32, u32, u32, vp]),
+        "dvn_msm_g1_windows_submit": (i32, [vp, vp, sz, sz, vp, u32, u32, u32, C.POINTER(i32)]),
+        "dvn_msm_g1_windows_collect": (i32, [vp, i32, vp]),
         "dvn_msm_combine_g1": (i32, [vp, vp, u32, u32, vp]),
         "dvn_ntt_domain": (i32, [vp, u32, C.POINTER(vp)]),
         "dvn_ntt_domain_free": (i32, [vp, vp]),
@@ -108,7 +110,7 @@ EXPORTED_SYMBOLS = [
     "dvn_init", "dvn_shutdown", "dvn_last_error", "dvn_version", "dvn_malloc", "dvn_free", "dvn_memcpy_h2d",
     "dvn_memcpy_d2h", "dvn_synchronize", "dvn_points_upload_g1", "dvn_points_upload_g2", "dvn_points_synthetic_g1",
     "dvn_points_synthetic_g2", "dvn_scalars_synthetic", "dvn_points_set_expanded", "dvn_points_download", "dvn_points_len", "dvn_points_free", "dvn_msm_g1", "dvn_msm_g2",
-    "dvn_msm_g1_submit", "dvn_msm_g1_collect", "dvn_msm_g2_submit", "dvn_msm_g2_collect", "dvn_msm_plan", "dvn_msm_plan_points", "dvn_msm_g1_windows", "dvn_msm_combine_g1", "dvn_ntt_domain", "dvn_ntt_domain_free", "dvn_ntt",
+    "dvn_msm_g1_submit", "dvn_msm_g1_collect", "dvn_msm_g2_submit", "dvn_msm_g2_collect", "dvn_msm_plan", "dvn_msm_plan_points", "dvn_msm_g1_windows", "dvn_msm_g1_windows_submit", "dvn_msm_g1_windows_collect", "dvn_msm_combine_g1", "dvn_ntt_domain", "dvn_ntt_domain_free", "dvn_ntt",
     "dvn_groth16_compute_h", "dvn_last_kernel_ms", "dvn_r1cs_synthetic", "dvn_r1cs_info", "dvn_r1cs_witness", "dvn_r1cs_free",
     "dvn_groth16_setup", "dvn_groth16_pk_info", "dvn_groth16_pk_free", "dvn_groth16_prove", "dvn_groth16_last_ms",
     "dvn_groth16_proof_abi_encode", "dvn_prover_use_gpu", "dvn_prover_set_use_gpu", "dvn_prover_reload_env", "dvn_prover_set_prover", "dvn_prover_set_cpu_backend",
@@ -284,6 +286,18 @@ class Context:
         sp, ns, fl = self._scalars(scalars, n)
         out = np.zeros((win_hi - win_lo, 16), dtype=np.uint64)
         self._chk(self.L.dvn_msm_g1_windows(self.h, pts.handle, off, ns, sp, fl, win_lo, win_hi, _host(out)))
+        return out
+
+    def msm_g1_windows_submit(self, pts: Points, scalars, win_lo: int, win_hi: int, off: int = 0, n: int | None = None):
+        sp, ns, fl = self._scalars(scalars, n)
+        t = C.c_int32()
+        self._chk(self.L.dvn_msm_g1_windows_submit(self.h, pts.handle, off, ns, sp, fl, win_lo, win_hi, C.byref(t)))
+        return t.value, win_hi - win_lo
+
+    def msm_g1_windows_collect(self, ticket) -> np.ndarray:
+        t, w = ticket
+        out = np.zeros((w, 16), dtype=np.uint64)
+        self._chk(self.L.dvn_msm_g1_windows_collect(self.h, t, _host(out)))
         return out
 
     def msm_combine_g1(self, window_sums: np.ndarray, window_bits: int) -> np.ndarray:

@@ -24,30 +24,36 @@ extern "C" int32_t dvn_msm_plan_points(const dvn_points* pts, size_t n, uint32_t
     *combine_bits = *window_bits;
     return DVN_OK;
 }
-extern "C" int32_t dvn_msm_g1_windows(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
-                                      uint32_t win_lo, uint32_t win_hi, uint64_t* window_sums) {
-    TRY(enter(ctx));
-    if (!pts || !window_sums || (!scalars && n)) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+// window-sharded MSM, asynchronous halves: submit queues windows [win_lo, win_hi) on a free lane, collect exports the
+// per-window sums (external-Montgomery X, Y, ZZ, ZZZ; infinity = all zero).  Expanded sets put the partial result in slot 0.
+static int32_t windows_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
+                              uint32_t win_lo, uint32_t win_hi, MsmLane** out) {
+    if (!pts || (!scalars && n)) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (pts->curve != 1) return fail(DVN_ERR_INVALID_ARG, "point set is not G1");
     if (off > pts->n || n > pts->n - off) return fail(DVN_ERR_INVALID_ARG, "len(points) != len(scalars)");
     const bool expanded = use_expanded(pts, n);
     u32 c, nwin;
     if (expanded) { c = pts->expand_c; nwin = pts->nexp; } else msm_plan(n, &c, &nwin);
     if (win_lo > win_hi || win_hi > nwin) return fail(DVN_ERR_INVALID_ARG, "window range [%u, %u) outside [0, %u)", win_lo, win_hi, nwin);
-    const u32 W = win_hi - win_lo;
-    if (W == 0) return DVN_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    std::vector<u32> sums((size_t)W * G1::XW, 0u);
-    if (n) {
-        MsmLane* L = nullptr;
-        TRY(lane_acquire(ctx, &L));
-        int32_t rc = expanded ? msm_expanded<G1>(ctx, *L, pts, off, n, scalars, flags, win_lo, win_hi)    // slot 0 = partial sum
-                              : msm_windows<G1>(ctx, *L, pts, off, n, scalars, flags, c, nwin, win_lo, win_hi);
-        if (rc != DVN_OK) { (void)hipStreamSynchronize(L->stream); L->busy = false; return rc; }
-        TRY(lane_wait(ctx, *L));
-        memcpy(sums.data(), L->h_sums, (size_t)(expanded ? 1 : W) * G1::XW * 4);
-    }
-    // export as external-Montgomery (X, Y, ZZ, ZZZ); infinity = all zero
+    MsmLane* L = nullptr;
+    TRY(lane_acquire(ctx, &L));
+    L->curve = 1; L->expanded = expanded; L->c = c; L->nwin = nwin; L->W = win_hi - win_lo;
+    int32_t rc = DVN_OK;
+    if (n && L->W) {
+        rc = expanded ? msm_expanded<G1>(ctx, *L, pts, off, n, scalars, flags, win_lo, win_hi)
+                      : msm_windows<G1>(ctx, *L, pts, off, n, scalars, flags, c, nwin, win_lo, win_hi);
+    } else L->nwin = 0;                                     // nothing queued
+    if (rc != DVN_OK) { (void)hipStreamSynchronize(L->stream); L->busy = false; return rc; }
+    *out = L;
+    return DVN_OK;
+}
+static int32_t windows_collect(dvn_ctx* ctx, MsmLane& L, uint64_t* window_sums) {
+    const u32 W = L.W;
+    std::vector<u32> sums((size_t)(W ? W : 1) * G1::XW, 0u);
+    if (L.nwin) {
+        TRY(lane_wait(ctx, L));
+        memcpy(sums.data(), L.h_sums, (size_t)(L.expanded ? 1 : W) * G1::XW * 4);
+    } else L.busy = false;
     u32* o = (u32*)window_sums;
     for (u32 w = 0; w < W; ++w) {
         G1::X p = G1::load_xyzz_internal(sums.data() + (size_t)w * G1::XW);
@@ -56,6 +62,33 @@ extern "C" int32_t dvn_msm_g1_windows(dvn_ctx* ctx, const dvn_points* pts, size_
         Ops<Fp>::to_ext(p.zz, o + w * 32 + 16); Ops<Fp>::to_ext(p.zzz, o + w * 32 + 24);
     }
     return DVN_OK;
+}
+extern "C" int32_t dvn_msm_g1_windows_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
+                                             uint32_t win_lo, uint32_t win_hi, int32_t* ticket) {
+    TRY(enter(ctx));
+    if (!ticket) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    MsmLane* L = nullptr;
+    TRY(windows_submit(ctx, pts, off, n, scalars, flags, win_lo, win_hi, &L));
+    *ticket = (int32_t)(L - ctx->lane) + 1;
+    return DVN_OK;
+}
+extern "C" int32_t dvn_msm_g1_windows_collect(dvn_ctx* ctx, int32_t ticket, uint64_t* window_sums) {
+    TRY(enter(ctx));
+    if (!window_sums || ticket < 1 || ticket > DVN_LANES) return fail(DVN_ERR_INVALID_ARG, "bad ticket");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    MsmLane& L = ctx->lane[ticket - 1];
+    if (!L.busy || L.curve != 1) return fail(DVN_ERR_INVALID_ARG, "ticket %d is not an outstanding window-sharded G1 MSM", ticket);
+    return windows_collect(ctx, L, window_sums);
+}
+extern "C" int32_t dvn_msm_g1_windows(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
+                                      uint32_t win_lo, uint32_t win_hi, uint64_t* window_sums) {
+    TRY(enter(ctx));
+    if (!window_sums) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    MsmLane* L = nullptr;
+    TRY(windows_submit(ctx, pts, off, n, scalars, flags, win_lo, win_hi, &L));
+    return windows_collect(ctx, *L, window_sums);
 }
 extern "C" int32_t dvn_msm_combine_g1(dvn_ctx* ctx, const uint64_t* window_sums, uint32_t nwin, uint32_t window_bits, uint64_t out_jac[12]) {
     (void)ctx;   /* pure host computation: ctx may be NULL (CPU-side tests of the sharded path) */

@@ -43,3 +43,26 @@ def sharded_msm_g1(ctx, pts, scalars, n: int, rank: int, world: int, dist=None, 
     sums = ctx.msm_g1_windows(pts, scalars, lo, hi, n=n)
     allsums = exchange_window_sums(sums, nwin, world, rank, dist, device)
     return ctx.msm_combine_g1(allsums, combine_bits)
+
+
+class ShardedMsmPipeline:
+    """Window-sharded G1 MSMs with two steps in flight per rank: the windows of step k+1 are queued on the GPU
+    (second lane) before the sums of step k are exchanged and combined, so the all-gather, the host combine and the
+    latency-bound tail of one step hide under the accumulate kernel of the next."""
+
+    def __init__(self, ctx, pts, n: int, rank: int, world: int, dist=None, device="cuda"):
+        self.ctx, self.pts, self.n, self.rank, self.world, self.dist, self.device = ctx, pts, n, rank, world, dist, device
+        _, self.nwin, self.combine_bits = ctx.msm_plan_points(pts, n)
+        self.lo, self.hi = window_slice(self.nwin, world, rank)
+        self.pending = []
+
+    def submit(self, scalars):
+        self.pending.append(self.ctx.msm_g1_windows_submit(self.pts, scalars, self.lo, self.hi, n=self.n))
+
+    def collect(self):
+        sums = self.ctx.msm_g1_windows_collect(self.pending.pop(0))
+        allsums = exchange_window_sums(sums, self.nwin, self.world, self.rank, self.dist, self.device)
+        return self.ctx.msm_combine_g1(allsums, self.combine_bits)
+
+    def in_flight(self) -> int:
+        return len(self.pending)

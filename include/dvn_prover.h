@@ -108,6 +108,11 @@ int32_t dvn_msm_plan(size_t n, uint32_t* window_bits, uint32_t* nwin);
 int32_t dvn_msm_plan_points(const dvn_points* pts, size_t n, uint32_t* window_bits, uint32_t* nwin, uint32_t* combine_bits);
 int32_t dvn_msm_g1_windows(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars_mont,
                            uint32_t flags, uint32_t win_lo, uint32_t win_hi, uint64_t* window_sums /* (win_hi-win_lo) x 16 */);
+/* asynchronous halves of dvn_msm_g1_windows (same lanes/tickets as dvn_msm_g1_submit): lets a rank queue the next
+ * step's windows while it exchanges and combines the previous step's sums */
+int32_t dvn_msm_g1_windows_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars_mont,
+                                  uint32_t flags, uint32_t win_lo, uint32_t win_hi, int32_t* ticket);
+int32_t dvn_msm_g1_windows_collect(dvn_ctx* ctx, int32_t ticket, uint64_t* window_sums /* (win_hi-win_lo) x 16 */);
 int32_t dvn_msm_combine_g1(dvn_ctx* ctx, const uint64_t* window_sums /* nwin x 16 */, uint32_t nwin, uint32_t window_bits,
                            uint64_t out_jac[12]);
 

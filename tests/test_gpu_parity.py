@@ -186,6 +186,26 @@ def test_msm_async_two_in_flight(ctx, orc, pkg):
     ctx.free(da); ctx.free(db); pts.free(); p2.free()
 
 
+def test_window_sharded_pipeline_single_process(ctx, orc, pkg):
+    """sharding.ShardedMsmPipeline with world = 1 semantics replaced by two fake ranks sharing this GPU: both ranks'
+    window slices are submitted asynchronously (two lanes), collected, concatenated and combined."""
+    from davinci_node_amd import sharding
+    n = 30000
+    ph = orc.g1_synthetic_points(51, n); pts = ctx.upload_g1(ph)
+    sc = orc.scalars(7, 0, n); d = ctx.to_device(sc)
+    _, nwin, cb = ctx.msm_plan_points(pts, n)
+    want = orc.msm_g1(ph, sc)
+    for world in (2, 4):
+        parts = []
+        slices = [sharding.window_slice(nwin, world, r) for r in range(world)]
+        for i in range(0, world, 2):                       # two tickets in flight at a time
+            t0 = ctx.msm_g1_windows_submit(pts, d, *slices[i], n=n)
+            t1 = ctx.msm_g1_windows_submit(pts, d, *slices[i + 1], n=n)
+            parts += [ctx.msm_g1_windows_collect(t0), ctx.msm_g1_windows_collect(t1)]
+        assert (aff1(orc, ctx.msm_combine_g1(np.concatenate(parts), cb)) == want).all()
+    ctx.free(d); pts.free()
+
+
 # ---- MSM G2 -----------------------------------------------------------------------------------------------------
 def test_msm_g2_golden_vectors(ctx, orc, vectors, conv):
     for case in vectors["msm_g2"]:
