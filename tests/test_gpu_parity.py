@@ -206,6 +206,45 @@ def test_window_sharded_pipeline_single_process(ctx, orc, pkg):
     ctx.free(d); pts.free()
 
 
+def test_thread_safety_concurrent_callers(ctx, orc):
+    """gnark issues its MSMs from concurrent goroutines and cgo calls arrive on arbitrary OS threads:
+    four threads hammer one context with MSMs and NTTs; every result must still be bit-exact."""
+    import threading
+    n = 6000
+    ph = orc.g1_synthetic_points(61, n); pts = ctx.upload_g1(ph)
+    scal = [orc.scalars(100 + i, i % 2, n) for i in range(4)]
+    want = [orc.msm_g1(ph, s) for s in scal]
+    dom = ctx.domain(10); x = orc.scalars(2, 0, 1 << 10); wx = orc.ntt(x, False, 0, False)
+    errors = []
+    def worker(i):
+        try:
+            for _ in range(6):
+                if not (aff1(orc, ctx.msm_g1(pts, scal[i])) == want[i]).all():
+                    errors.append(("msm", i))
+                y = x.copy(); ctx.ntt(dom, y, False, 0, False)
+                if not (y == wx).all():
+                    errors.append(("ntt", i))
+        except Exception as e:                                    # noqa: BLE001
+            errors.append((repr(e), i))
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for th in ths: th.start()
+    for th in ths: th.join()
+    assert errors == []
+    dom.free(); pts.free()
+
+
+def test_context_lifecycle_and_second_context(pkg, orc):
+    """init/shutdown repeatedly; two live contexts on one device are independent."""
+    for _ in range(3):
+        c = pkg.Context(0); c.close()
+    a, b = pkg.Context(0), pkg.Context(0)
+    ph = orc.g1_synthetic_points(71, 500); sc = orc.scalars(3, 0, 500)
+    pa, pb = a.upload_g1(ph), b.upload_g1(ph)
+    ra, rb = a.msm_g1(pa, sc), b.msm_g1(pb, sc)
+    assert (ra == rb).all() and (orc.g1_jac_to_affine(ra) == orc.msm_g1(ph, sc)).all()
+    pa.free(); pb.free(); a.close(); b.close()
+
+
 # ---- MSM G2 -----------------------------------------------------------------------------------------------------
 def test_msm_g2_golden_vectors(ctx, orc, vectors, conv):
     for case in vectors["msm_g2"]:
