@@ -89,6 +89,7 @@ def load_library():
         "dvn_groth16_prove": (i32, [vp, vp, vp, u32, vp, vp, vp]),
         "dvn_groth16_last_ms": (i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "dvn_groth16_proof_abi_encode": (i32, [vp, vp, vp, vp]),
+        "dvn_pedersen_commit": (i32, [vp, vp, vp, vp, sz, u32, vp, vp]),
         "dvn_prover_use_gpu": (i32, []),
         "dvn_prover_set_use_gpu": (None, [i32]),
         "dvn_prover_reload_env": (None, []),
@@ -113,7 +114,7 @@ EXPORTED_SYMBOLS = [
     "dvn_msm_g1_submit", "dvn_msm_g1_collect", "dvn_msm_g2_submit", "dvn_msm_g2_collect", "dvn_msm_plan", "dvn_msm_plan_points", "dvn_msm_g1_windows", "dvn_msm_g1_windows_submit", "dvn_msm_g1_windows_collect", "dvn_msm_combine_g1", "dvn_ntt_domain", "dvn_ntt_domain_free", "dvn_ntt",
     "dvn_groth16_compute_h", "dvn_last_kernel_ms", "dvn_r1cs_synthetic", "dvn_r1cs_info", "dvn_r1cs_witness", "dvn_r1cs_free",
     "dvn_groth16_setup", "dvn_groth16_pk_info", "dvn_groth16_pk_free", "dvn_groth16_prove", "dvn_groth16_last_ms",
-    "dvn_groth16_proof_abi_encode", "dvn_prover_use_gpu", "dvn_prover_set_use_gpu", "dvn_prover_reload_env", "dvn_prover_set_prover", "dvn_prover_set_cpu_backend",
+    "dvn_groth16_proof_abi_encode", "dvn_pedersen_commit", "dvn_prover_use_gpu", "dvn_prover_set_use_gpu", "dvn_prover_reload_env", "dvn_prover_set_prover", "dvn_prover_set_cpu_backend",
     "dvn_prover_last_backend", "dvn_prover_prove", "dvn_prover_setup",
 ]
 
@@ -326,6 +327,13 @@ class Context:
         out = np.zeros((dom.n, 4), dtype=np.uint64)
         self._chk(self.L.dvn_groth16_compute_h(self.h, dom.handle, _host(a), _host(b), _host(c), a.shape[0], _host(out), 0))
         return out
+
+    def pedersen_commit(self, basis: Points, basis_exp_sigma: Points, values: np.ndarray):
+        """(commitment, pok) G1Affine images: MSM(Basis, values), MSM(BasisExpSigma, values)."""
+        values = np.ascontiguousarray(values, dtype=np.uint64).reshape(-1, 4)
+        c, k = np.zeros(8, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
+        self._chk(self.L.dvn_pedersen_commit(self.h, basis.handle, basis_exp_sigma.handle, _host(values), values.shape[0], 0, _host(c), _host(k)))
+        return c, k
 
     def last_kernel_ms(self, which: int = 0) -> float:
         ms = C.c_float(); self._chk(self.L.dvn_last_kernel_ms(self.h, which, C.byref(ms))); return float(ms.value)

@@ -499,3 +499,42 @@ extern "C" int32_t dvn_groth16_proof_abi_encode(const uint64_t proof[32], const 
     if (commitment_pok) { fp_ext_to_be32((const u32*)commitment_pok, out + 320); fp_ext_to_be32((const u32*)commitment_pok + 8, out + 352); }
     return DVN_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------------
+// Pedersen commitment + proof of knowledge (gnark-crypto ecc/bn254/fr/pedersen ProvingKey.Commit /
+// ProveKnowledge, called from gnark's BSB22 commitment hint inside groth16.Prove): two G1 MSMs over the committed
+// wire values, against Basis and BasisExpSigma.  With a single commitment (statetransition has exactly one,
+// /root/reference/solidity/solidity.go:57-65) BatchProve's fold is the identity, so pok_out IS CommitmentPok.
+// Outputs are G1Affine images (8 x uint64, infinity = zeros).  Both MSMs are in flight together (two lanes).
+// ------------------------------------------------------------------------------------------------------
+extern "C" int32_t dvn_pedersen_commit(dvn_ctx* ctx, const dvn_points* basis, const dvn_points* basis_exp_sigma,
+                                       const uint64_t* values_mont, size_t n, uint32_t flags,
+                                       uint64_t commitment_out[8], uint64_t pok_out[8]) {
+    TRY(enter(ctx));
+    if (!basis || !basis_exp_sigma || (!values_mont && n) || !commitment_out || !pok_out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    if (basis->curve != 1 || basis_exp_sigma->curve != 1) return fail(DVN_ERR_INVALID_ARG, "bases must be G1 point sets");
+    if (n > basis->n || n > basis_exp_sigma->n) return fail(DVN_ERR_INVALID_ARG, "len(values) exceeds the basis");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    u32* d_vals = nullptr;
+    const u32* vals = (const u32*)values_mont;
+    if (!(flags & 1) && n) {               // host values: one upload shared by both MSMs
+        HIP_TRY(hipMalloc((void**)&d_vals, n * 32));
+        hipError_t e = hipMemcpy(d_vals, values_mont, n * 32, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(d_vals); (void)hipGetLastError(); return fail(DVN_ERR_DEVICE, "upload failed: %s", hipGetErrorString(e)); }
+        vals = d_vals;
+    }
+    typedef dvn_host::HG1 H1;
+    MsmLane *la = nullptr, *lb = nullptr;
+    H1::X c, k;
+    int32_t rc = dvn_internal_msm_submit_g1(ctx, basis, 0, n, vals, &la);
+    if (rc == DVN_OK) rc = dvn_internal_msm_submit_g1(ctx, basis_exp_sigma, 0, n, vals, &lb);
+    if (rc == DVN_OK) rc = dvn_internal_msm_collect_g1(ctx, la, &c); else if (la) { H1::X t; (void)dvn_internal_msm_collect_g1(ctx, la, &t); }
+    if (rc == DVN_OK) rc = dvn_internal_msm_collect_g1(ctx, lb, &k);
+    if (d_vals) (void)hipFree(d_vals);
+    if (rc != DVN_OK) return rc;
+    uint64_t j[12];
+    H1::write_jac(c, j); memcpy(commitment_out, j, 64); if (H1::is_inf(c)) memset(commitment_out, 0, 64);
+    H1::write_jac(k, j); memcpy(pok_out, j, 64); if (H1::is_inf(k)) memset(pok_out, 0, 64);
+    return DVN_OK;
+}

@@ -158,6 +158,13 @@ int32_t dvn_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witn
 /* device time of the last dvn_groth16_prove: computeH part (incl. the matrix-vector "solve"), the five MSMs, total */
 int32_t dvn_groth16_last_ms(const dvn_groth16_pk* pk, float* ms_h, float* ms_msm, float* ms_total);
 
+/* Pedersen commitment and its proof of knowledge (gnark-crypto fr/pedersen ProvingKey.Commit /
+ * ProveKnowledge, reached from the BSB22 commitment hint of groth16.Prove): commitment = MSM(Basis, values),
+ * pok = MSM(BasisExpSigma, values); with one commitment (statetransition) the BatchProve fold is the identity.
+ * values: n x 4 uint64 Montgomery (host; device pointer if flags & 1).  Outputs: G1Affine images. */
+int32_t dvn_pedersen_commit(dvn_ctx* ctx, const dvn_points* basis, const dvn_points* basis_exp_sigma,
+                            const uint64_t* values_mont, size_t n, uint32_t flags,
+                            uint64_t commitment_out[8], uint64_t pok_out[8]);
 /* Solidity ABI image (uint256[8], uint256[2], uint256[2]) of a proof, as /root/reference/solidity/solidity.go:29-73,
  * 85-116 builds it for the on-chain verifier: big-endian words, G2 coordinates A1 before A0.
  * commitment / commitment_pok: G1Affine images or NULL (zeros).  Host only. */

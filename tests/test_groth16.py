@@ -87,3 +87,19 @@ def test_proof_abi_encoding_matches_reference_layout(pkg, opy, orc):
     assert L.dvn_groth16_proof_abi_encode(proof.ctypes.data, cm.ctypes.data, None, out.ctypes.data) == 0
     words = [int.from_bytes(bytes(out[32 * i:32 * i + 32]), "big") for i in range(12)]
     assert words == [ar[0], ar[1], bs[0][1], bs[0][0], bs[1][1], bs[1][0], krs[0], krs[1], com[0], com[1], 0, 0]
+
+
+@pytest.mark.gpu
+def test_pedersen_commit_and_pok(ctx, opy, orc):
+    """Row a14: commitment = MSM(Basis, v), pok = MSM(BasisExpSigma, v) with BasisExpSigma = sigma * Basis, hence
+    pok == sigma * commitment (what the verifier's pairing check e(C, -sigma G2) e(pok, G2) = 1 relies on)."""
+    o = opy
+    n, sigma = 700, 0x1234567890ABCDEF1234567
+    basis = orc.g1_synthetic_points(81, n)
+    bes = np.array([orc.g1_mul(basis[i], sigma) for i in range(n)], dtype=np.uint64)
+    v = orc.scalars(9, 1, n)
+    pb, ps = ctx.upload_g1(basis), ctx.upload_g1(bes)
+    c, k = ctx.pedersen_commit(pb, ps, v)
+    assert (c == orc.msm_g1(basis, v)).all() and (k == orc.msm_g1(bes, v)).all()
+    assert (k == orc.g1_mul(c, sigma)).all()
+    pb.free(); ps.free()
