@@ -1,0 +1,256 @@
+"""Curve-generic big-integer oracle (TEST INFRASTRUCTURE ONLY; see oracle/bn254_py.py header for the rules).
+
+Extends the BN254 oracle to the other curves the reference proves on: BLS12-377
+(voteverifier, `/root/reference/spec/params/params.go:21-27`; GPU dispatch at `prover/prover_gpu.go:36-43`).
+Same conventions as gnark-crypto: Element = little-endian u64 limbs in Montgomery form with R = 2^(64 * limbs)
+(4 limbs for the 253/254-bit fields, 6 for BLS12-377's 377-bit base field); E2 = a0 + a1*u with u^2 = -BETA;
+affine infinity = all-zero image; fft.Domain DIF/DIT/coset semantics with the curve's multiplicative generator.
+
+PARITY UNPINNED: no vectors for these primitives exist in the reference.  The constants below were cross-checked here:
+r | #E(Fp) via r*G1 = O, G1 on y^2 = x^3 + 1, root_of_unity == gen^((r-1)/2^47) == gnark-crypto's hard-coded
+8065159656716812877374967518403273466521432693661810619979959746626482506078, twist coefficient == 1/u = (0, -1/5).
+"""
+from __future__ import annotations
+from . import bn254_py as b
+
+MASK64 = (1 << 64) - 1
+
+
+class PrimeField:
+    def __init__(self, p):
+        self.p = p
+        self.zero, self.one = 0, 1
+
+    def add(self, a, c): return (a + c) % self.p
+    def sub(self, a, c): return (a - c) % self.p
+    def mul(self, a, c): return (a * c) % self.p
+    def neg(self, a): return (-a) % self.p
+    def inv(self, a): return pow(a, -1, self.p)
+    def is_zero(self, a): return a % self.p == 0
+    def from_int(self, k): return k % self.p
+
+
+class QuadExt:
+    """Fp[u]/(u^2 + beta), elements (a0, a1)."""
+
+    def __init__(self, p, beta):
+        self.p, self.beta = p, beta
+        self.zero, self.one = (0, 0), (1, 0)
+
+    def add(self, a, c): return ((a[0] + c[0]) % self.p, (a[1] + c[1]) % self.p)
+    def sub(self, a, c): return ((a[0] - c[0]) % self.p, (a[1] - c[1]) % self.p)
+    def mul(self, a, c):
+        return ((a[0] * c[0] - self.beta * a[1] * c[1]) % self.p, (a[0] * c[1] + a[1] * c[0]) % self.p)
+    def neg(self, a): return ((-a[0]) % self.p, (-a[1]) % self.p)
+    def inv(self, a):
+        d = pow(a[0] * a[0] + self.beta * a[1] * a[1], -1, self.p)
+        return ((a[0] * d) % self.p, (-a[1] * d) % self.p)
+    def is_zero(self, a): return a[0] % self.p == 0 and a[1] % self.p == 0
+    def from_int(self, k): return (k % self.p, 0)
+
+
+def _tonelli(n, p):
+    """Square root mod p (p odd prime), or None."""
+    n %= p
+    if n == 0:
+        return 0
+    if pow(n, (p - 1) // 2, p) != 1:
+        return None
+    q, s = p - 1, 0
+    while q % 2 == 0:
+        q //= 2; s += 1
+    z = 2
+    while pow(z, (p - 1) // 2, p) != p - 1:
+        z += 1
+    m, c, t, r_ = s, pow(z, q, p), pow(n, q, p), pow(n, (q + 1) // 2, p)
+    while t != 1:
+        i, t2 = 0, t
+        while t2 != 1:
+            t2 = t2 * t2 % p; i += 1
+        bb = pow(c, 1 << (m - i - 1), p)
+        m, c = i, bb * bb % p
+        t, r_ = t * c % p, r_ * bb % p
+    return r_
+
+
+class Suite:
+    """One pairing-friendly curve: base/scalar fields, G1: y^2 = x^3 + b, G2 over QuadExt: y^2 = x^3 + b2."""
+
+    def __init__(self, name, p, r, b_g1, beta, b_g2, g1_gen, fr_gen, two_adicity):
+        self.name, self.p, self.r = name, p, r
+        self.fp, self.fp2 = PrimeField(p), QuadExt(p, beta)
+        self.b_g1, self.b_g2, self.g1_gen = b_g1, b_g2, g1_gen
+        self.fp_limbs = (p.bit_length() + 63) // 64
+        self.fr_limbs = (r.bit_length() + 63) // 64
+        self.fr_gen, self.two_adicity = fr_gen, two_adicity
+        self.root = pow(fr_gen, (r - 1) >> two_adicity, r)
+
+    # ---- Montgomery images -------------------------------------------------------------------------------------
+    def fp_to_mont(self, x): return (x << (64 * self.fp_limbs)) % self.p
+    def fp_from_mont(self, x): return x * pow(1 << (64 * self.fp_limbs), -1, self.p) % self.p
+    def fr_to_mont(self, x): return (x << (64 * self.fr_limbs)) % self.r
+    def fr_from_mont(self, x): return x * pow(1 << (64 * self.fr_limbs), -1, self.r) % self.r
+
+    def limbs(self, x, n): return [(x >> (64 * i)) & MASK64 for i in range(n)]
+
+    def g1_to_limbs(self, pt):
+        n = self.fp_limbs
+        if pt is None:
+            return [0] * (2 * n)
+        return self.limbs(self.fp_to_mont(pt[0]), n) + self.limbs(self.fp_to_mont(pt[1]), n)
+
+    def g2_to_limbs(self, pt):
+        n = self.fp_limbs
+        if pt is None:
+            return [0] * (4 * n)
+        out = []
+        for c in (pt[0][0], pt[0][1], pt[1][0], pt[1][1]):
+            out += self.limbs(self.fp_to_mont(c), n)
+        return out
+
+    def fr_to_limbs(self, x): return self.limbs(self.fr_to_mont(x), self.fr_limbs)
+    def fr_from_limbs(self, ls): return self.fr_from_mont(b.from_limbs(ls))
+
+    # ---- groups (generic chord-and-tangent law of bn254_py) ----------------------------------------------------------
+    def g1_on_curve(self, pt): return b.ec_is_on_curve(self.fp, self.b_g1, pt)
+    def g2_on_curve(self, pt): return b.ec_is_on_curve(self.fp2, self.b_g2, pt)
+    def g1_add(self, a, c): return b.ec_add(self.fp, a, c)
+    def g2_add(self, a, c): return b.ec_add(self.fp2, a, c)
+    def g1_neg(self, a): return b.ec_neg(self.fp, a)
+    def g2_neg(self, a): return b.ec_neg(self.fp2, a)
+    def g1_mul(self, a, k): return b.ec_mul(self.fp, a, k)
+    def g2_mul(self, a, k): return b.ec_mul(self.fp2, a, k)
+
+    def msm(self, F, pts, ks):
+        if len(pts) != len(ks):
+            raise ValueError("len(points) != len(scalars)")
+        acc = None
+        for pt, k in zip(pts, ks):
+            acc = b.ec_add(F, acc, b.ec_mul(F, pt, k % self.r))
+        return acc
+
+    def g1_msm(self, pts, ks): return self.msm(self.fp, pts, ks)
+    def g2_msm(self, pts, ks): return self.msm(self.fp2, pts, ks)
+
+    def fr_at(self, seed, i):
+        """i-th canonical scalar of SplitMix64 stream `seed` (256-bit value mod r), as bn254_py.fr_at."""
+        v = 0
+        for k in range(4):
+            v |= b.splitmix_at(seed, 4 * i + k) << (64 * k)
+        return v % self.r
+
+    def synthetic_g1_points(self, seed, n):
+        s0, s1 = self.fr_at(seed, 0), self.fr_at(seed, 1)
+        p0, d = self.g1_mul(self.g1_gen, s0), self.g1_mul(self.g1_gen, s1)
+        out, cur = [], p0
+        for _ in range(n):
+            out.append(cur); cur = self.g1_add(cur, d)
+        return out
+
+    def fp2_sqrt(self, a):
+        """sqrt in Fp[u]/(u^2+beta) by the norm method; None if a is not a square."""
+        p, beta = self.p, self.fp2.beta
+        a0, a1 = a
+        if a1 % p == 0:
+            s = _tonelli(a0, p)
+            if s is not None:
+                return (s, 0)
+            s = _tonelli(a0 * pow(-beta, -1, p) % p, p)        # a0 = -beta * t^2  ->  sqrt = t*u
+            return None if s is None else (0, s)
+        n = _tonelli((a0 * a0 + beta * a1 * a1) % p, p)
+        if n is None:
+            return None
+        for nn in (n, (-n) % p):
+            x2 = (a0 + nn) * pow(2, -1, p) % p
+            x = _tonelli(x2, p)
+            if x is not None and x != 0:
+                y = a1 * pow(2 * x, -1, p) % p
+                if self.fp2.mul((x, y), (x, y)) == (a0 % p, a1 % p):
+                    return (x, y)
+        return None
+
+    def g2_some_point(self, start=1):
+        """A point on the twist (not necessarily in the r-torsion: the group law under test does not care)."""
+        x0 = start
+        while True:
+            x = (x0, 1)
+            rhs = self.fp2.add(self.fp2.mul(self.fp2.mul(x, x), x), self.b_g2)
+            y = self.fp2_sqrt(rhs)
+            if y is not None:
+                return (x, y)
+            x0 += 1
+
+    def synthetic_g2_points(self, seed, n):
+        base = self.g2_some_point(1 + seed % 97)
+        s0, s1 = self.fr_at(seed, 0), self.fr_at(seed, 1)
+        p0, d = self.g2_mul(base, s0), self.g2_mul(base, s1)
+        out, cur = [], p0
+        for _ in range(n):
+            out.append(cur); cur = self.g2_add(cur, d)
+        return out
+
+    # ---- fr/fft Domain with gnark semantics (bn254_py.Domain restated for any scalar field) ---------------------------
+    def domain(self, m):
+        return GenericDomain(self, m)
+
+
+class GenericDomain:
+    def __init__(self, suite: Suite, m: int):
+        n = 1
+        while n < m:
+            n <<= 1
+        self.n, self.log_n, self.r = n, n.bit_length() - 1, suite.r
+        assert self.log_n <= suite.two_adicity
+        self.gen = pow(suite.root, 1 << (suite.two_adicity - self.log_n), self.r)
+        self.gen_inv = pow(self.gen, -1, self.r)
+        self.card_inv = pow(n, -1, self.r)
+        self.coset, self.coset_inv = suite.fr_gen, pow(suite.fr_gen, -1, self.r)
+
+    def _dif(self, a, w):
+        n, R = self.n, self.r
+        half, stride = n >> 1, 1
+        while half >= 1:
+            for start in range(0, n, 2 * half):
+                for j in range(half):
+                    x, y = a[start + j], a[start + j + half]
+                    a[start + j] = (x + y) % R
+                    a[start + j + half] = ((x - y) * pow(w, j * stride, R)) % R
+            half >>= 1; stride <<= 1
+
+    def _dit(self, a, w):
+        n, R = self.n, self.r
+        half, stride = 1, n >> 1
+        while half < n:
+            for start in range(0, n, 2 * half):
+                for j in range(half):
+                    x = a[start + j]
+                    y = (a[start + j + half] * pow(w, j * stride, R)) % R
+                    a[start + j] = (x + y) % R
+                    a[start + j + half] = (x - y) % R
+            half <<= 1; stride >>= 1
+
+    def fft(self, a, decimation, coset=False):
+        if coset:
+            for i in range(self.n):
+                k = b.bitrev(i, self.log_n) if decimation == b.DIT else i
+                a[i] = (a[i] * pow(self.coset, k, self.r)) % self.r
+        (self._dif if decimation == b.DIF else self._dit)(a, self.gen)
+
+    def fft_inverse(self, a, decimation, coset=False):
+        (self._dif if decimation == b.DIF else self._dit)(a, self.gen_inv)
+        for i in range(self.n):
+            s = self.card_inv
+            if coset:
+                k = b.bitrev(i, self.log_n) if decimation == b.DIF else i
+                s = (s * pow(self.coset_inv, k, self.r)) % self.r
+            a[i] = (a[i] * s) % self.r
+
+
+_P377 = 0x01AE3A4617C510EAC63B05C06CA1493B1A22D9F300F5138F1EF3622FBA094800170B5D44300000008508C00000000001
+_R377 = 0x12AB655E9A2CA55660B44D1E5C37B00159AA76FED00000010A11800000000001
+BLS12_377 = Suite(
+    "bls12-377", _P377, _R377, b_g1=1, beta=5, b_g2=(0, (-pow(5, -1, _P377)) % _P377),
+    g1_gen=(0x008848DEFE740A67C8FC6225BF87FF5485951E2CAA9D41BB188282C8BD37CB5CD5481512FFCD394EEAB9B16EB21BE9EF,
+            0x01914A69C5102EFF1F674F5D30AFEEC4BD7FB348CA3E52D96D182AD44FB82305C2FE3D3634A9591AFD82DE55559C8EA6),
+    fr_gen=22, two_adicity=47)
+BN254 = Suite("bn254", b.P, b.R, b_g1=3, beta=1, b_g2=b.B_G2, g1_gen=b.G1_GEN, fr_gen=5, two_adicity=28)
