@@ -162,5 +162,8 @@ template <class F> struct Curve {
 
 typedef Curve<Fp> G1;
 typedef Curve<Fp2> G2;
+// BLS12-377 (voteverifier curve): same a = 0 group law over 14-limb base-field elements
+typedef Curve<Fp377> G1_377;
+typedef Curve<Fp2_377> G2_377;
 
 }  // namespace dvn

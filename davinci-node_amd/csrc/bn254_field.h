@@ -316,11 +316,15 @@ template <class C> DVN_HD Fe<C> fe_pow_u64(const Fe<C>& a, u64 e) {
 }
 // a^(p-2) (Fermat inversion); 0 -> 0 as gnark's Inverse
 template <class C> DVN_HD Fe<C> fe_inv(const Fe<C>& a) {
-    // exponent p-2 as 29-bit limbs: p(0) is odd and >= 3 for every field here, so only limb 0 changes
+    // exponent p-2 as 29-bit limbs (borrow propagated: BLS12-377's moduli are 1 mod 2^46)
     u32 e[C::NL];
+    u32 borrow = 2;
 #pragma unroll
-    for (int k = 0; k < C::NL; ++k) e[k] = C::p(k);
-    e[0] -= 2;
+    for (int k = 0; k < C::NL; ++k) {
+        const u32 pk = C::p(k);
+        if (pk >= borrow) { e[k] = pk - borrow; borrow = 0; }
+        else { e[k] = pk + (1u << LB) - borrow; borrow = 1; }
+    }
     Fe<C> acc = fe_one<C>();
     for (int k = C::NL - 1; k >= 0; --k) {
         u32 limb = 0;

@@ -44,7 +44,6 @@ struct dvn_groth16_pk {
 // ------------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------------
-static __device__ __forceinline__ Fr ld_fr_internal(const u32* __restrict__ p) { return ld_fr(p); }   // same packing
 
 // out[row] = sum_k coef[k] * w[idx[k]]; w are gnark Montgomery words (read as x*2^-5 internal), coef true internal:
 // the product is again a gnark Montgomery word.
@@ -54,8 +53,8 @@ static __global__ void k_r1cs_matvec(const u32* __restrict__ ptr, const u32* __r
     if (r >= rows) return;
     Fr acc = fe_zero<FrCfg>();
     for (u32 k = ptr[r]; k < ptr[r + 1]; ++k)
-        acc = fe_add<FrCfg>(acc, fe_mul<FrCfg>(ld_fr(coef + (size_t)k * 8), ld_fr(w + (size_t)idx[k] * 8)));
-    st_fr(acc, out + (size_t)r * 8);
+        acc = fe_add<FrCfg>(acc, fe_mul<FrCfg>(ld_fr<FrCfg>(coef + (size_t)k * 8), ld_fr<FrCfg>(w + (size_t)idx[k] * 8)));
+    st_fr<FrCfg>(acc, out + (size_t)r * 8);
 }
 static __global__ void k_gather_fr(const u32* __restrict__ src, const u32* __restrict__ idx, u32* __restrict__ dst, size_t count) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -68,10 +67,10 @@ static __global__ void k_gather_fr(const u32* __restrict__ src, const u32* __res
 static __global__ void k_lagrange(u32* __restrict__ out, const u32* __restrict__ consts, size_t n) {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    const Fr w = ld_fr(consts), tau = ld_fr(consts + 8), zn = ld_fr(consts + 16);
+    const Fr w = ld_fr<FrCfg>(consts), tau = ld_fr<FrCfg>(consts + 8), zn = ld_fr<FrCfg>(consts + 16);
     const Fr wj = fe_pow_u64<FrCfg>(w, (u64)j);
     const Fr den = fe_inv<FrCfg>(fe_sub<FrCfg>(tau, wj));
-    st_fr(fe_mul<FrCfg>(fe_mul<FrCfg>(zn, wj), den), out + j * 8);
+    st_fr<FrCfg>(fe_mul<FrCfg>(fe_mul<FrCfg>(zn, wj), den), out + j * 8);
 }
 // column evaluation: out[i] = sum_k coef[k] * L[row[k]] over the entries of wire i (CSC of one R1CS matrix)
 static __global__ void k_col_eval(const u32* __restrict__ ptr, const u32* __restrict__ row, const u32* __restrict__ coef,
@@ -80,8 +79,8 @@ static __global__ void k_col_eval(const u32* __restrict__ ptr, const u32* __rest
     if (i >= cols) return;
     Fr acc = fe_zero<FrCfg>();
     for (u32 k = ptr[i]; k < ptr[i + 1]; ++k)
-        acc = fe_add<FrCfg>(acc, fe_mul<FrCfg>(ld_fr(coef + (size_t)k * 8), ld_fr(L + (size_t)row[k] * 8)));
-    st_fr(acc, out + (size_t)i * 8);
+        acc = fe_add<FrCfg>(acc, fe_mul<FrCfg>(ld_fr<FrCfg>(coef + (size_t)k * 8), ld_fr<FrCfg>(L + (size_t)row[k] * 8)));
+    st_fr<FrCfg>(acc, out + (size_t)i * 8);
 }
 // K_i = (beta * At_i + alpha * Bt_i + Ct_i) / delta for i >= n_public; consts = {alpha, beta, 1/delta}
 static __global__ void k_key_k(const u32* __restrict__ at, const u32* __restrict__ bt, const u32* __restrict__ ct,
@@ -89,17 +88,17 @@ static __global__ void k_key_k(const u32* __restrict__ at, const u32* __restrict
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
     const size_t i = (size_t)first + t;
-    const Fr alpha = ld_fr(consts), beta = ld_fr(consts + 8), dinv = ld_fr(consts + 16);
-    Fr v = fe_add<FrCfg>(fe_add<FrCfg>(fe_mul<FrCfg>(beta, ld_fr(at + i * 8)), fe_mul<FrCfg>(alpha, ld_fr(bt + i * 8))), ld_fr(ct + i * 8));
-    st_fr(fe_mul<FrCfg>(v, dinv), out + (size_t)t * 8);
+    const Fr alpha = ld_fr<FrCfg>(consts), beta = ld_fr<FrCfg>(consts + 8), dinv = ld_fr<FrCfg>(consts + 16);
+    Fr v = fe_add<FrCfg>(fe_add<FrCfg>(fe_mul<FrCfg>(beta, ld_fr<FrCfg>(at + i * 8)), fe_mul<FrCfg>(alpha, ld_fr<FrCfg>(bt + i * 8))), ld_fr<FrCfg>(ct + i * 8));
+    st_fr<FrCfg>(fe_mul<FrCfg>(v, dinv), out + (size_t)t * 8);
 }
 // Z'_i = zdt * tau^(bitrev(i)): gnark computes Z_i = (tau^n - 1)/delta * tau^i and bit-reverses the POINT array
 static __global__ void k_key_z(u32* __restrict__ out, const u32* __restrict__ consts /* {tau, zdt} */, u32 log_n) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (1u << log_n)) return;
-    const Fr tau = ld_fr(consts), zdt = ld_fr(consts + 8);
+    const Fr tau = ld_fr<FrCfg>(consts), zdt = ld_fr<FrCfg>(consts + 8);
     const u32 e = __brev(i) >> (32 - log_n);
-    st_fr(fe_mul<FrCfg>(zdt, fe_pow_u64<FrCfg>(tau, (u64)e)), out + (size_t)i * 8);
+    st_fr<FrCfg>(fe_mul<FrCfg>(zdt, fe_pow_u64<FrCfg>(tau, (u64)e)), out + (size_t)i * 8);
 }
 // fixed-base table: table[(w * 256 + d)] = d * 2^(8w) * G (affine internal), d in 1..255, w in 0..31
 template <class Cv> __global__ void k_fb_table(u32* __restrict__ table, const u32* __restrict__ gen) {
@@ -119,7 +118,7 @@ template <class Cv> __global__ void k_fixed_base(const u32* __restrict__ table, 
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     u32 kw[8];
-    fe_pack<FrCfg>(fe_canonical<FrCfg>(fe_mul<FrCfg>(ld_fr(scalars + i * 8), fe_small<FrCfg>(1))), kw);   // internal -> integer
+    fe_pack<FrCfg>(fe_canonical<FrCfg>(fe_mul<FrCfg>(ld_fr<FrCfg>(scalars + i * 8), fe_small<FrCfg>(1))), kw);   // internal -> integer
     typename Cv::X acc = Cv::infinity();
     for (u32 w = 0; w < 32; ++w) {
         const u32 d = (kw[w >> 2] >> (8 * (w & 3))) & 255;
@@ -236,7 +235,7 @@ static int32_t fixed_base_points(dvn_ctx* ctx, const typename Cv::A& gen, const 
     dvn_points* p = new (std::nothrow) dvn_points();
     if (!p) return fail(DVN_ERR_OOM, "host allocation failed");
     p->curve = curve; p->n = count;
-    expand_plan(curve, count, &p->expand_c, &p->nexp);
+    expand_plan(curve, count, 254, &p->expand_c, &p->nexp);
     u32 *table = nullptr, *dgen = nullptr;
     u32 hg[Cv::AW];
     Cv::store_affine_internal(gen, hg);

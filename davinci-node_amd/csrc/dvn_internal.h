@@ -48,6 +48,7 @@ struct dvn_ctx {
     bool force_fail = false;
 };
 struct dvn_points {
+    int suite = 0;            // 0 = BN254, 1 = BLS12-377
     int curve = 1;            // 1 = G1, 2 = G2
     size_t n = 0;
     u32* d = nullptr;         // internal affine image: nexp rows of n points; row w holds 2^(expand_c * w) * P_i
@@ -57,15 +58,16 @@ struct dvn_points {
 // Default expansion policy (measured on MI355X, tools/gpu_cmp.py): G2 sets of >= 2^17 points win 10-35 % from the
 // one-bucket-set layout (their accumulate dominates); for G1 the two-pass sort of 2^19 buckets eats the 19 % saved
 // additions, so G1 sets stay plain unless dvn_points_set_expanded is called.  DVN_MSM_EXPAND=0 disables it globally.
-static inline void expand_plan(int curve, size_t n, u32* c, u32* nexp) {
+static inline void expand_plan(int curve, size_t n, u32 scalar_bits, u32* c, u32* nexp) {
     static const int enabled = []() { const char* v = getenv("DVN_MSM_EXPAND"); return (v && v[0] == '0') ? 0 : 1; }();
     *c = 0; *nexp = 1;
     if (!enabled || curve != 2) return;
     if (n >= ((size_t)1 << 19)) *c = 20;
     else if (n >= ((size_t)1 << 17)) *c = 18;
-    if (*c) *nexp = 254 / *c + 1;
+    if (*c) *nexp = scalar_bits / *c + 1;
 }
 struct dvn_domain {
+    int suite = 0;            // 0 = BN254 Fr, 1 = BLS12-377 Fr
     u32 log_n = 0;
     u32* tw_fwd = nullptr;    // per-stage tables, n-1 entries (8 words each), entry (n - (n>>s)) + k = w^(k<<s)
     u32* tw_inv = nullptr;

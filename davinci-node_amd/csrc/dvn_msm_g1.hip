@@ -146,7 +146,7 @@ extern "C" int32_t dvn_scalars_synthetic(dvn_ctx* ctx, uint64_t seed, int kind, 
     if (kind != 0 && kind != 1) return fail(DVN_ERR_INVALID_ARG, "kind must be 0 (uniform) or 1 (witness-like)");
     if (n == 0) return DVN_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
-    k_scalars_synthetic<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>((u32*)d_out, n, seed, kind);
+    k_scalars_synthetic<FrCfg><<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>((u32*)d_out, n, seed, kind);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return DVN_OK;

@@ -86,3 +86,52 @@ void hc_g2_add(const uint32_t* a, const uint32_t* b, uint32_t* out) {
     G2::affine_to_ext(G2::to_affine(G2::add_mixed(G2::from_affine(G2::affine_from_ext(a)), G2::affine_from_ext(b))), out);
 }
 }
+
+// ---- BLS12-377 (14 x 29-bit limbs, external 6 x u64; Fe2 with u^2 = -5) --------------------------------------------
+template <class C> static void bin12(const uint32_t* a, const uint32_t* b, uint32_t* r, int op) {
+    u32 wa[C::EW], wb[C::EW], wr[C::EW]; memcpy(wa, a, 4 * C::EW); memcpy(wb, b, 4 * C::EW);
+    Fe<C> x = fe_from_ext_mont<C>(wa), y = fe_from_ext_mont<C>(wb), z;
+    switch (op) {
+        case 0: z = fe_mul<C>(x, y); break;
+        case 1: z = fe_add<C>(x, y); break;
+        case 2: z = fe_sub<C>(x, y); break;
+        case 3: z = fe_sqr<C>(x); break;
+        case 4: z = fe_inv<C>(x); break;
+        case 5: z = fe_neg<C>(x); break;
+        default: z = fe_dbl<C>(x); break;
+    }
+    fe_to_ext_mont<C>(z, wr); memcpy(r, wr, 4 * C::EW);
+}
+template <class Cv> static void msm_naive(const uint32_t* pts, const uint32_t* k, size_t n, uint32_t* out) {
+    typename Cv::X acc = Cv::infinity();
+    for (size_t i = 0; i < n; ++i) {
+        typename Cv::A p = Cv::affine_from_ext(pts + (size_t)Cv::AW * i);
+        typename Cv::X t = Cv::infinity();
+        for (int b = 255; b >= 0; --b) {
+            t = Cv::dbl(t);
+            if ((k[8 * i + (b >> 5)] >> (b & 31)) & 1) t = Cv::add_mixed(t, p);
+        }
+        acc = Cv::add(acc, t);
+    }
+    Cv::affine_to_ext(Cv::to_affine(acc), out);
+}
+extern "C" {
+void hc377_fp_op(const uint32_t* a, const uint32_t* b, uint32_t* r, int op) { bin12<Fp377Cfg>(a, b, r, op); }
+void hc377_fr_op(const uint32_t* a, const uint32_t* b, uint32_t* r, int op) { bin12<Fr377Cfg>(a, b, r, op); }
+void hc377_fr_ext_to_canonical(const uint32_t* a, uint32_t* r) {
+    u32 wa[8], wr[8]; memcpy(wa, a, 32);
+    fe_pack<Fr377Cfg>(fe_ext_mont_to_canonical<Fr377Cfg>(wa), wr); memcpy(r, wr, 32);
+}
+void hc377_g1_msm_naive(const uint32_t* pts, const uint32_t* k, size_t n, uint32_t* out) { msm_naive<G1_377>(pts, k, n, out); }
+void hc377_g2_msm_naive(const uint32_t* pts, const uint32_t* k, size_t n, uint32_t* out) { msm_naive<G2_377>(pts, k, n, out); }
+// lazily reduced accumulator chain over G1-377 (the k_accumulate loop body)
+void hc377_g1_acc_chain(const uint32_t* pts, const uint32_t* idx, size_t n, uint32_t* out) {
+    G1_377::X acc = G1_377::infinity();
+    for (size_t i = 0; i < n; ++i) {
+        G1_377::A p = G1_377::affine_from_ext(pts + (size_t)G1_377::AW * (idx[i] & 0x7fffffffu));
+        if (idx[i] & 0x80000000u) p = G1_377::neg(p);
+        acc = G1_377::acc_add_mixed(acc, p);
+    }
+    G1_377::affine_to_ext(G1_377::to_affine(G1_377::acc_normalize(acc)), out);
+}
+}

@@ -5,6 +5,16 @@
 #include "msm_kernels.h"
 #include "host_fast.h"
 
+// scalar field of each group, and the finishing arithmetic used on the host
+template <class Cv> struct ScalarOf;
+template <> struct ScalarOf<G1> { typedef FrCfg S; };
+template <> struct ScalarOf<G2> { typedef FrCfg S; };
+template <> struct ScalarOf<G1_377> { typedef Fr377Cfg S; };
+template <> struct ScalarOf<G2_377> { typedef Fr377Cfg S; };
+template <class Cv> struct SuiteOf { static constexpr int value = 0; };          // 0 = BN254, 1 = BLS12-377
+template <> struct SuiteOf<G1_377> { static constexpr int value = 1; };
+template <> struct SuiteOf<G2_377> { static constexpr int value = 1; };
+
 // ------------------------------------------------------------------------------------------------------
 // points
 // ------------------------------------------------------------------------------------------------------
@@ -16,7 +26,8 @@ template <class Cv> static int32_t points_upload(dvn_ctx* ctx, const uint64_t* x
     dvn_points* p = new (std::nothrow) dvn_points();
     if (!p) return fail(DVN_ERR_OOM, "host allocation failed");
     p->curve = curve; p->n = n;
-    expand_plan(curve, n, &p->expand_c, &p->nexp);
+    p->suite = SuiteOf<Cv>::value;
+    expand_plan(curve, n, ScalarOf<Cv>::S::BITS, &p->expand_c, &p->nexp);
     size_t bytes = n * Cv::AW * 4;
     hipError_t e = hipMalloc((void**)&p->d, bytes ? bytes * p->nexp : 16);
     if (e != hipSuccess) { delete p; (void)hipGetLastError(); return fail(DVN_ERR_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
@@ -46,7 +57,8 @@ template <class Cv> static int32_t points_synthetic(dvn_ctx* ctx, uint64_t seed,
     dvn_points* p = new (std::nothrow) dvn_points();
     if (!p) return fail(DVN_ERR_OOM, "host allocation failed");
     p->curve = curve; p->n = n;
-    expand_plan(curve, n, &p->expand_c, &p->nexp);
+    p->suite = SuiteOf<Cv>::value;
+    expand_plan(curve, n, ScalarOf<Cv>::S::BITS, &p->expand_c, &p->nexp);
     u32* dbs = nullptr;
     hipError_t e = hipMalloc((void**)&p->d, n ? n * Cv::AW * 4 * p->nexp : 16);
     if (e == hipSuccess) e = hipMalloc((void**)&dbs, sizeof(hb));
@@ -81,14 +93,14 @@ template <class Cv> static int32_t points_download(dvn_ctx* ctx, const dvn_point
 // ------------------------------------------------------------------------------------------------------
 // MSM
 // ------------------------------------------------------------------------------------------------------
-static void msm_plan(size_t n, u32* c_out, u32* nwin_out) {
+static void msm_plan(size_t n, u32* c_out, u32* nwin_out, u32 bits = 254) {
     // minimise nwin * (n + 3 * 2^(c-1)): n mixed additions per window plus ~3 additions per bucket to reduce
     u32 best = 8; double bc = 1e300;
     for (u32 c = 6; c <= 16; ++c) {
-        double cost = (double)(254 / c + 1) * ((double)n + 3.0 * (double)(1u << (c - 1)));
+        double cost = (double)(bits / c + 1) * ((double)n + 3.0 * (double)(1u << (c - 1)));
         if (cost < bc) { bc = cost; best = c; }
     }
-    *c_out = best; *nwin_out = 254 / best + 1;
+    *c_out = best; *nwin_out = bits / best + 1;
 }
 
 // Segment length for k_accumulate: every lane executes exactly `seg` additions.  Measured (tools/gpu_seg.py, 2^22):
@@ -172,7 +184,7 @@ static int32_t msm_windows(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, size
     }
     HIP_TRY(hipEventRecord(L.ev[0], st));
     HIP_TRY(hipMemsetAsync(totals, 0, (size_t)(W + 1) * 4, st));
-    k_digits16<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_scalars, n, c, win_lo, win_hi, digits);
+    k_digits16<typename ScalarOf<Cv>::S><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_scalars, n, c, win_lo, win_hi, digits);
     DBG_SYNC("k_digits16");
     k_tile_hist<<<W * ntiles, 1024, hist_lds, st>>>(digits, n, nb, tile_len, ntiles, hist);
     DBG_SYNC("k_tile_hist");
@@ -268,7 +280,7 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
     if (dbg) { fprintf(stderr, "[dvn] msm(expanded) n=%zu c=%u W=%u nb=%u hb=%u seg=%u nseg=%u ntiles=%u ws=%zu\n", n, c, W, nb, hb, seg, nseg, ntiles, cs.off); fflush(stderr); }
     HIP_TRY(hipEventRecord(L.ev[0], st));
     HIP_TRY(hipMemsetAsync(totals, 0, 16, st));
-    k_digits32<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_scalars, n, c, win_lo, win_hi, digits);
+    k_digits32<typename ScalarOf<Cv>::S><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_scalars, n, c, win_lo, win_hi, digits);
     DBG_SYNC("k_digits32");
     k_p1_hist<<<ntiles, 1024, (size_t)hb * 4, st>>>(digits, total, tile_len, hb, hist1);
     DBG_SYNC("k_p1_hist");
@@ -304,7 +316,7 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
 // (re)build the expanded table of an existing set for window size c (0 = back to a plain set)
 template <class Cv> static int32_t points_set_expanded(dvn_ctx* ctx, dvn_points* p, u32 c) {
     if (c != 0 && (c < 11 || c > 24)) return fail(DVN_ERR_INVALID_ARG, "window_bits must be 0 or in [11, 24]");
-    const u32 nexp = c ? 254 / c + 1 : 1;
+    const u32 nexp = c ? ScalarOf<Cv>::S::BITS / c + 1 : 1;
     if ((size_t)nexp * p->n >= ((size_t)1 << 31)) return fail(DVN_ERR_INVALID_ARG, "expanded table too large");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     u32* nd = nullptr;
@@ -343,7 +355,30 @@ template <class Cv> static void write_jac(const typename Cv::X& p, uint64_t* out
     O::to_ext(a.x, w); O::to_ext(a.y, w + FW); O::to_ext(O::one(), w + 2 * FW);
 }
 
-template <class Cv> struct FastHost;
+// generic finishing arithmetic: the device headers compiled for the host (used where no 64-bit-limb host code exists)
+template <class Cv> struct SlowHostG {
+    typedef typename Cv::X X;
+    static X infinity() { return Cv::infinity(); }
+    static bool is_inf(const X& p) { return Cv::is_inf(p); }
+    static X add(const X& a, const X& b) { return Cv::add(a, b); }
+    static X horner(const u32* sums, u32 nwin, u32 c) {
+        X acc = Cv::infinity();
+        for (int w = (int)nwin - 1; w >= 0; --w) {
+            for (u32 k = 0; k < c; ++k) acc = Cv::dbl(acc);
+            acc = Cv::add(acc, Cv::load_xyzz_internal(sums + (size_t)w * Cv::XW));
+        }
+        return acc;
+    }
+    static void write_jac(const X& p, uint64_t* out) {            // affine normal form with Z = 1, infinity = (1, 1, 0)
+        typedef typename Cv::O O;
+        u32* w = (u32*)out;
+        const int FW = O::WORDS;
+        if (Cv::is_inf(p)) { O::to_ext(O::one(), w); O::to_ext(O::one(), w + FW); O::to_ext(O::zero(), w + 2 * FW); return; }
+        typename Cv::A a = Cv::to_affine(p);
+        O::to_ext(a.x, w); O::to_ext(a.y, w + FW); O::to_ext(O::one(), w + 2 * FW);
+    }
+};
+template <class Cv> struct FastHost { typedef SlowHostG<Cv> G; };
 template <> struct FastHost<G1> { typedef dvn_host::HG1 G; };
 template <> struct FastHost<G2> { typedef dvn_host::HG2 G; };
 
@@ -384,7 +419,7 @@ static int32_t msm_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_
         L->expanded = true; L->c = 0; L->nwin = 1;
         rc = msm_expanded<Cv>(ctx, *L, pts, off, n, scalars, flags, 0, pts->nexp);
     } else {
-        u32 c, nwin; msm_plan(n, &c, &nwin);
+        u32 c, nwin; msm_plan(n, &c, &nwin, ScalarOf<Cv>::S::BITS);
         L->expanded = false; L->c = c; L->nwin = nwin;
         rc = msm_windows<Cv>(ctx, *L, pts, off, n, scalars, flags, c, nwin, 0, nwin);
     }
@@ -414,7 +449,7 @@ template <class Cv>
 static int32_t msm_full(dvn_ctx* ctx, const dvn_points* pts, int curve, size_t off, size_t n, const uint64_t* scalars, uint32_t flags, uint64_t* out_jac) {
     TRY(enter(ctx));
     if (!pts || !out_jac || (!scalars && n)) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
-    if (pts->curve != curve) return fail(DVN_ERR_INVALID_ARG, "point set is G%d, call is G%d", pts->curve, curve);
+    if (pts->curve != curve || pts->suite != SuiteOf<Cv>::value) return fail(DVN_ERR_INVALID_ARG, "point set is G%d of suite %d, call is G%d of suite %d", pts->curve, pts->suite, curve, SuiteOf<Cv>::value);
     typedef typename FastHost<Cv>::G HG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     MsmLane* L = nullptr;

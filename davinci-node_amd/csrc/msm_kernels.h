@@ -101,7 +101,8 @@ __device__ __forceinline__ u64 dev_splitmix_at(u64 seed, u64 index) {
     return z ^ (z >> 31);
 }
 // kind 0: uniform mod r; kind 1: 40 % zero, 25 % one, 25 % < 2^64, 10 % uniform.  Output gnark Montgomery words.
-static __global__ void k_scalars_synthetic(u32* __restrict__ out, size_t n, u64 seed, int kind) {
+template <class S> __global__ void k_scalars_synthetic(u32* __restrict__ out, size_t n, u64 seed, int kind) {
+    static_assert(S::EW == 8, "scalar fields are 4 x u64");
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -115,8 +116,14 @@ static __global__ void k_scalars_synthetic(u32* __restrict__ out, size_t n, u64 
     else if (mode == 3) {
         for (int k = 0; k < 4; ++k) { u64 v = dev_splitmix_at(seed, 4 * i + k); w[2 * k] = (u32)v; w[2 * k + 1] = (u32)(v >> 32); }
         // reduce the 256-bit value mod r (< 6r): repeated conditional subtraction
-        const u32 rm[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
-        for (int rep = 0; rep < 6; ++rep) {
+        u32 rm[8];
+        { u32 t[8]; Fe<S> pm;
+#pragma unroll
+          for (int j = 0; j < S::NL; ++j) pm.v[j] = S::p(j);
+          fe_pack<S>(pm, t);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) rm[j] = t[j]; }
+        for (int rep = 0; rep < 16; ++rep) {
             bool ge = true;
             for (int j = 7; j >= 0; --j) { if (w[j] > rm[j]) { ge = true; break; } if (w[j] < rm[j]) { ge = false; break; } }
             if (!ge) break;
@@ -125,23 +132,23 @@ static __global__ void k_scalars_synthetic(u32* __restrict__ out, size_t n, u64 
         }
     }
     u32 o[8];
-    fe_to_ext_mont<FrCfg>(fe_from_canonical<FrCfg>(fe_unpack<FrCfg>(w)), o);
+    fe_to_ext_mont<S>(fe_from_canonical<S>(fe_unpack<S>(w)), o);
     store_words16(out + i * 8, o, 8);
 }
 
 // ---- digits -> per-window counting sort, all ranking done with LDS atomics (no global atomics) ------------------
 // Signed c-bit digits in [-2^(c-1), 2^(c-1) - 1] stored as int16 (c <= 16): digits[(w - win_lo) * n + i].
 // Bucket index of a non-zero digit d is |d| - 1 in [0, 2^(c-1)).
-static __global__ void k_digits16(const u32* __restrict__ scalars, size_t n, u32 c, u32 win_lo, u32 win_hi,
+template <class S> __global__ void k_digits16(const u32* __restrict__ scalars, size_t n, u32 c, u32 win_lo, u32 win_hi,
                                   int16_t* __restrict__ digits) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 w[8];
     load_words16(scalars + i * 8, w, 8);
-    Fr k = fe_ext_mont_to_canonical<FrCfg>(w);
+    Fe<S> k = fe_ext_mont_to_canonical<S>(w);
     u32 kw[9];
     {
-        u32 t[8]; fe_pack<FrCfg>(k, t);
+        u32 t[8]; fe_pack<S>(k, t);
 #pragma unroll
         for (int j = 0; j < 8; ++j) kw[j] = t[j];
         kw[8] = 0;
@@ -257,15 +264,15 @@ template <class Cv> __global__ void k_points_expand(u32* __restrict__ table, siz
     }
 }
 // signed c-bit digits (c <= 24) as int32: digits[(w - win_lo) * n + i] in [-2^(c-1), 2^(c-1) - 1]
-static __global__ void k_digits32(const u32* __restrict__ scalars, size_t n, u32 c, u32 win_lo, u32 win_hi, int* __restrict__ digits) {
+template <class S> __global__ void k_digits32(const u32* __restrict__ scalars, size_t n, u32 c, u32 win_lo, u32 win_hi, int* __restrict__ digits) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 w[8];
     load_words16(scalars + i * 8, w, 8);
-    Fr k = fe_ext_mont_to_canonical<FrCfg>(w);
+    Fe<S> k = fe_ext_mont_to_canonical<S>(w);
     u32 kw[9];
     {
-        u32 t[8]; fe_pack<FrCfg>(k, t);
+        u32 t[8]; fe_pack<S>(k, t);
 #pragma unroll
         for (int j = 0; j < 8; ++j) kw[j] = t[j];
         kw[8] = 0;

@@ -1,0 +1,129 @@
+// Host drivers of fft.Domain / FFT / FFTInverse, templated on the scalar-field config S (FrCfg for BN254, Fr377Cfg for
+// BLS12-377); included by dvn_ntt.hip and dvn_bls12377.hip.
+#pragma once
+#include "dvn_internal.h"
+#include "ntt_kernels.h"
+
+// per-field constants of gnark-crypto's fft.Domain: 2-adic root of unity (canonical words), its order, the coset shift
+template <class S> struct DomainConsts;
+template <> struct DomainConsts<FrCfg> {      // w_{2^28} = 5^((r-1)/2^28), FrMultiplicativeGen = 5
+    static constexpr u32 ADICITY = 28; static constexpr u64 COSET_GEN = 5; static constexpr int SUITE = 0;
+    static const u64* root() { static const u64 r[4] = {0x9bd61b6e725b19f0ULL, 0x402d111e41112ed4ULL, 0x00e0a7eb8ef62abcULL, 0x2a3c09f0a58a7e85ULL}; return r; }
+};
+template <> struct DomainConsts<Fr377Cfg> {   // w_{2^47} = 22^((r-1)/2^47) = gnark-crypto's 8065159656716812877374967518403273466521432693661810619979959746626482506078
+    static constexpr u32 ADICITY = 47; static constexpr u64 COSET_GEN = 22; static constexpr int SUITE = 1;
+    static const u64* root() { static const u64 r[4] = {0x476ef4a4ec2a895eULL, 0x9b506ee363e3f04aULL, 0x60c69477d1a8a12fULL, 0x11d4b7f60cb92cc1ULL}; return r; }
+};
+
+// ------------------------------------------------------------------------------------------------------
+// NTT
+// ------------------------------------------------------------------------------------------------------
+template <class S> static Fe<S> fr_from_u64(u64 v) {
+    u32 w[8] = {(u32)v, (u32)(v >> 32), 0, 0, 0, 0, 0, 0};
+    return fe_from_canonical<S>(fe_unpack<S>(w));
+}
+template <class S> static Fe<S> fr_root_of_unity(u32 log_n) {      // square the 2-adic root down to order 2^log_n
+    Fe<S> w = fe_from_canonical<S>(fe_unpack<S>(*(const u32(*)[8])DomainConsts<S>::root()));
+    for (u32 i = log_n; i < DomainConsts<S>::ADICITY; ++i) w = fe_sqr<S>(w);
+    return w;
+}
+template <class S> static void fr_store_internal(const Fe<S>& v, u32* w) { u32 t[8]; fe_pack<S>(fe_canonical<S>(v), t); memcpy(w, t, 32); }
+
+template <class S> static int32_t launch_powers(dvn_ctx* ctx, u32* d_out, const Fe<S>& base, const Fe<S>& first, size_t count, u32* d_scratch16) {
+    u32 h[16]; fr_store_internal<S>(base, h); fr_store_internal<S>(first, h + 8);
+    HIP_TRY(hipMemcpyAsync(d_scratch16, h, 64, hipMemcpyHostToDevice, ctx->stream));
+    const u32 chunk = 64;
+    size_t threads = (count + chunk - 1) / chunk;
+    k_powers<S><<<(unsigned)((threads + 63) / 64), 64, 0, ctx->stream>>>(d_out, d_scratch16, count, chunk);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // h goes out of scope
+    return DVN_OK;
+}
+
+template <class S> static int32_t ntt_domain_create(dvn_ctx* ctx, uint32_t log_n, dvn_domain** out) {
+    TRY(enter(ctx));
+    if (!out) return fail(DVN_ERR_INVALID_ARG, "out is NULL");
+    if (log_n < 1 || log_n > 27 || log_n > DomainConsts<S>::ADICITY) return fail(DVN_ERR_INVALID_ARG, "log_n = %u outside [1, 27]", log_n);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    dvn_domain* d = new (std::nothrow) dvn_domain();
+    if (!d) return fail(DVN_ERR_OOM, "host allocation failed");
+    d->log_n = log_n; d->suite = DomainConsts<S>::SUITE;
+    const size_t n = (size_t)1 << log_n;
+    d->lo_bits = log_n < 10 ? log_n : 10;
+    const size_t nlo = (size_t)1 << d->lo_bits, nhi = n >> d->lo_bits;
+    u32* scratch = nullptr;
+    int32_t rc = DVN_OK;
+    auto alloc = [&](u32** p, size_t entries) -> int32_t { HIP_TRY(hipMalloc((void**)p, entries * 32)); return DVN_OK; };
+    do {
+        if ((rc = alloc(&d->tw_fwd, n)) || (rc = alloc(&d->tw_inv, n)) || (rc = alloc(&d->g_lo, nlo)) || (rc = alloc(&d->g_hi, nhi)) ||
+            (rc = alloc(&d->gi_lo, nlo)) || (rc = alloc(&d->gi_hi, nhi)) || (rc = alloc(&d->card_inv, 1)) || (rc = alloc(&d->h_consts, 2)) ||
+            (rc = alloc(&scratch, 2))) break;
+        const Fe<S> one = fe_one<S>();
+        const Fe<S> w = fr_root_of_unity<S>(log_n), wi = fe_inv<S>(w);
+        Fe<S> ws = w, wis = wi;
+        for (u32 s = 0; s < log_n && rc == DVN_OK; ++s) {
+            const size_t half = n >> (s + 1), offs = n - (n >> s);
+            if ((rc = launch_powers<S>(ctx, d->tw_fwd + offs * 8, ws, one, half, scratch))) break;
+            if ((rc = launch_powers<S>(ctx, d->tw_inv + offs * 8, wis, one, half, scratch))) break;
+            ws = fe_sqr<S>(ws); wis = fe_sqr<S>(wis);
+        }
+        if (rc) break;
+        const Fe<S> g = fr_from_u64<S>(DomainConsts<S>::COSET_GEN), gi = fe_inv<S>(g), ninv = fe_inv<S>(fr_from_u64<S>(n));
+        if ((rc = launch_powers<S>(ctx, d->g_lo, g, one, nlo, scratch))) break;
+        if ((rc = launch_powers<S>(ctx, d->g_hi, fe_pow_u64<S>(g, nlo), one, nhi, scratch))) break;
+        if ((rc = launch_powers<S>(ctx, d->gi_lo, gi, ninv, nlo, scratch))) break;
+        if ((rc = launch_powers<S>(ctx, d->gi_hi, fe_pow_u64<S>(gi, nlo), one, nhi, scratch))) break;
+        u32 h[24];
+        fr_store_internal<S>(ninv, h);
+        // den = 1/(g^n - 1); k1 = den * 2^5 (internal), k2 = den
+        const Fe<S> den = fe_inv<S>(fe_sub<S>(fe_pow_u64<S>(g, n), one));
+        fr_store_internal<S>(fe_mul<S>(den, fr_from_u64<S>(1u << S::EXT_SHIFT)), h + 8);
+        fr_store_internal<S>(den, h + 16);
+        hipError_t e = hipMemcpy(d->card_inv, h, 32, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d->h_consts, h + 8, 64, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipGetLastError(); rc = fail(DVN_ERR_DEVICE, "domain constant upload failed: %s", hipGetErrorString(e)); }
+    } while (0);
+    if (scratch) (void)hipFree(scratch);
+    if (rc != DVN_OK) {
+        std::string keep = tl_error;
+        u32* ptrs[] = {d->tw_fwd, d->tw_inv, d->g_lo, d->g_hi, d->gi_lo, d->gi_hi, d->card_inv, d->h_consts};
+        for (u32* p : ptrs) if (p) (void)hipFree(p);
+        delete d;
+        tl_error = keep;
+        return rc;
+    }
+    *out = d;
+    return DVN_OK;
+}
+
+// in-place transform of device data; asynchronous on ctx->stream
+template <class S> static int32_t ntt_device(dvn_ctx* ctx, const dvn_domain* d, u32* data, int inverse, int decimation, int coset) {
+    const u32 log_n = d->log_n;
+    const u32 npass = (log_n + 7) / 8;
+    const u32 base = log_n / npass, rem = log_n % npass;
+    u32 ks[8];
+    for (u32 p = 0; p < npass; ++p) ks[p] = base + (p < rem ? 1 : 0);
+    const u32* tw = inverse ? d->tw_inv : d->tw_fwd;
+    NttScale none{nullptr, nullptr, 0, 0, 0, 0};
+    NttScale sc = none;
+    if (!inverse && coset) sc = NttScale{d->g_lo, d->g_hi, d->lo_bits, 2, decimation == DVN_DIT, 1};
+    if (inverse && !coset) sc = NttScale{d->card_inv, nullptr, 0, 1, 0, 2};
+    if (inverse && coset) sc = NttScale{d->gi_lo, d->gi_hi, d->lo_bits, 2, decimation == DVN_DIF, 2};
+    // stage ranges in execution order
+    for (u32 p = 0; p < npass; ++p) {
+        u32 sa, sb;
+        if (decimation == DVN_DIF) { sa = 0; for (u32 q = 0; q < p; ++q) sa += ks[q]; sb = sa + ks[p]; }
+        else { sb = log_n; for (u32 q = 0; q < p; ++q) sb -= ks[q]; sa = sb - ks[p]; }
+        const u32 K = sb - sa;
+        u32 log_i = 3;
+        while (K + log_i > log_n) --log_i;                 // tile must not exceed the array
+        while (K + log_i > 11) --log_i;                    // <= 2048 elements = 64 KiB of LDS
+        const u32 tiles = (u32)(((size_t)1 << log_n) >> (K + log_i));
+        const size_t lds = ((size_t)1 << (K + log_i)) * 32;
+        NttScale use = none;
+        if (sc.mode && ((sc.when == 1 && p == 0) || (sc.when == 2 && p == npass - 1))) use = sc;
+        k_ntt_pass<S><<<tiles, 512, lds, ctx->stream>>>(data, tw, log_n, sa, sb, decimation == DVN_DIT, log_i, use);
+        HIP_TRY(hipGetLastError());
+    }
+    return DVN_OK;
+}

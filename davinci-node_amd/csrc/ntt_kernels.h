@@ -19,34 +19,34 @@
 
 namespace dvn {
 
-__device__ __forceinline__ Fr ld_fr(const u32* __restrict__ p) {
+template <class S> __device__ __forceinline__ Fe<S> ld_fr(const u32* __restrict__ p) {
     uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 4);
     u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    return fe_unpack<FrCfg>(w);
+    return fe_unpack<S>(w);
 }
 // weak form -> canonical -> 8 words
-__device__ __forceinline__ void st_fr(const Fr& v, u32* __restrict__ p) {
+template <class S> __device__ __forceinline__ void st_fr(const Fe<S>& v, u32* __restrict__ p) {
     u32 w[8];
-    fe_pack<FrCfg>(fe_canonical<FrCfg>(v), w);
+    fe_pack<S>(fe_canonical<S>(v), w);
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     *reinterpret_cast<uint4*>(p + 4) = make_uint4(w[4], w[5], w[6], w[7]);
 }
 // LDS staging keeps weak form (no canonicalisation between stages)
-__device__ __forceinline__ void st_fr_weak(const Fr& v, u32* p) {
+template <class S> __device__ __forceinline__ void st_fr_weak(const Fe<S>& v, u32* p) {
     u32 w[8];
-    fe_pack<FrCfg>(v, w);
+    fe_pack<S>(v, w);
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     *reinterpret_cast<uint4*>(p + 4) = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
 // out[k] = base^(k) * first, k < count; thread handles `chunk` consecutive entries.  base/first internal form.
-static __global__ void k_powers(u32* __restrict__ out, const u32* __restrict__ base_first, size_t count, u32 chunk) {
+template <class S> __global__ void k_powers(u32* __restrict__ out, const u32* __restrict__ base_first, size_t count, u32 chunk) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t lo = t * chunk;
     if (lo >= count) return;
     size_t hi = lo + chunk < count ? lo + chunk : count;
-    Fr base = ld_fr(base_first), cur = fe_mul<FrCfg>(fe_pow_u64<FrCfg>(base, (u64)lo), ld_fr(base_first + 8));
-    for (size_t k = lo; k < hi; ++k) { st_fr(cur, out + k * 8); cur = fe_mul<FrCfg>(cur, base); }
+    Fe<S> base = ld_fr<S>(base_first), cur = fe_mul<S>(fe_pow_u64<S>(base, (u64)lo), ld_fr<S>(base_first + 8));
+    for (size_t k = lo; k < hi; ++k) { st_fr<S>(cur, out + k * 8); cur = fe_mul<S>(cur, base); }
 }
 
 struct NttScale {
@@ -58,24 +58,25 @@ struct NttScale {
     int when;          // 1 = at load (pre-scale), 2 = at store (post-scale)
 };
 
-__device__ __forceinline__ Fr ntt_scale_factor(const NttScale& sc, u32 i, u32 log_n) {
-    if (sc.mode == 1) return ld_fr(sc.lo);
+template <class S> __device__ __forceinline__ Fe<S> ntt_scale_factor(const NttScale& sc, u32 i, u32 log_n) {
+    if (sc.mode == 1) return ld_fr<S>(sc.lo);
     const u32 e = sc.bitrev ? (__brev(i) >> (32 - log_n)) : i;
-    Fr f = ld_fr(sc.lo + (size_t)(e & ((1u << sc.lo_bits) - 1)) * 8);
-    if (log_n > sc.lo_bits) f = fe_mul<FrCfg>(f, ld_fr(sc.hi + (size_t)(e >> sc.lo_bits) * 8));
+    Fe<S> f = ld_fr<S>(sc.lo + (size_t)(e & ((1u << sc.lo_bits) - 1)) * 8);
+    if (log_n > sc.lo_bits) f = fe_mul<S>(f, ld_fr<S>(sc.hi + (size_t)(e >> sc.lo_bits) * 8));
     return f;
 }
 
 // values < 4p (the in-pass invariant) -> canonical -> 8 words
-__device__ __forceinline__ void st_fr4(const Fr& v, u32* __restrict__ p) { st_fr(fe_csub<FrCfg, 2>(v), p); }
+template <class S> __device__ __forceinline__ void st_fr4(const Fe<S>& v, u32* __restrict__ p) { st_fr<S>(fe_csub<S, 2>(v), p); }
 
 // stages [sa, sb) of a 2^log_n transform; dit = 0: ascending s (DIF), dit = 1: descending s (DIT).
 // Two stages per LDS round trip (radix-4 units held in registers); values in LDS are kept below 4p ("loose", limbs
 // normalised), so differences feed the twiddle multiplication after ONE carry pass and sums need one conditional
 // subtraction of 4p -- the multiplication itself tolerates operands up to 13p (bn254_field.h).
-static __global__ __launch_bounds__(512) void k_ntt_pass(u32* __restrict__ data, const u32* __restrict__ tw, u32 log_n,
+template <class S> __global__ __launch_bounds__(512) void k_ntt_pass(u32* __restrict__ data, const u32* __restrict__ tw, u32 log_n,
                                                   u32 sa, u32 sb, int dit, u32 log_i, NttScale sc) {
-    typedef FrCfg C;
+    typedef S C;
+    typedef Fe<S> Fr;
     extern __shared__ __align__(16) u32 lds[];
     const u32 K = sb - sa, Lb = log_n - sb, I = 1u << log_i;
     const u32 E = I << K;
@@ -86,9 +87,9 @@ static __global__ __launch_bounds__(512) void k_ntt_pass(u32* __restrict__ data,
     for (u32 le = threadIdx.x; le < E; le += blockDim.x) {
         const u32 q = le & (I - 1), D = le >> log_i, sp = sp0 + q;
         const u32 gi = ((sp >> Lb) << (Lb + K)) | (D << Lb) | (sp & inner_mask);
-        Fr v = ld_fr(data + (size_t)gi * 8);
-        if (sc.mode && sc.when == 1) v = fe_mul<C>(v, ntt_scale_factor(sc, gi, log_n));
-        st_fr_weak(v, lds + (size_t)le * 8);
+        Fr v = ld_fr<S>(data + (size_t)gi * 8);
+        if (sc.mode && sc.when == 1) v = fe_mul<C>(v, ntt_scale_factor<S>(sc, gi, log_n));
+        st_fr_weak<S>(v, lds + (size_t)le * 8);
     }
     __syncthreads();
     // ---- radix-4 rounds: executed stages t and t + 1
@@ -110,32 +111,32 @@ static __global__ __launch_bounds__(512) void k_ntt_pass(u32* __restrict__ data,
             u32* p01 = lds + (size_t)(((Db | (1u << dlo)) << log_i) | q) * 8;
             u32* p10 = lds + (size_t)(((Db | (2u << dlo)) << log_i) | q) * 8;
             u32* p11 = lds + (size_t)(((Db | (3u << dlo)) << log_i) | q) * 8;
-            const Fr x00 = ld_fr(p00), x01 = ld_fr(p01), x10 = ld_fr(p10), x11 = ld_fr(p11);
+            const Fr x00 = ld_fr<S>(p00), x01 = ld_fr<S>(p01), x10 = ld_fr<S>(p10), x11 = ld_fr<S>(p11);
             if (!dit) {
                 // stage s pairs over the HIGH bit (distance 2 << dlo), twiddle depends on the low bit;
                 // stage s+1 pairs over the LOW bit, one twiddle for the whole unit
-                const Fr wa0 = ld_fr(tab1 + (size_t)((low << Lb) | inner) * 8);
-                const Fr wa1 = ld_fr(tab1 + (size_t)((((1u << dlo) | low) << Lb) | inner) * 8);
-                const Fr wb = ld_fr(tab2 + (size_t)((low << Lb) | inner) * 8);
+                const Fr wa0 = ld_fr<S>(tab1 + (size_t)((low << Lb) | inner) * 8);
+                const Fr wa1 = ld_fr<S>(tab1 + (size_t)((((1u << dlo) | low) << Lb) | inner) * 8);
+                const Fr wb = ld_fr<S>(tab2 + (size_t)((low << Lb) | inner) * 8);
                 const Fr A0 = fe_csub<C, 4>(fe_add_lazy<C>(x00, x10)), A1 = fe_csub<C, 4>(fe_add_lazy<C>(x01, x11));
                 const Fr B0 = fe_mul<C>(fe_sub_lazy<C, 4>(x00, x10), wa0), B1 = fe_mul<C>(fe_sub_lazy<C, 4>(x01, x11), wa1);
-                st_fr_weak(fe_csub<C, 4>(fe_add_lazy<C>(A0, A1)), p00);
-                st_fr_weak(fe_mul<C>(fe_sub_lazy<C, 4>(A0, A1), wb), p01);
-                st_fr_weak(fe_add_lazy<C>(B0, B1), p10);
-                st_fr_weak(fe_mul<C>(fe_sub_lazy<C, 2>(B0, B1), wb), p11);
+                st_fr_weak<S>(fe_csub<C, 4>(fe_add_lazy<C>(A0, A1)), p00);
+                st_fr_weak<S>(fe_mul<C>(fe_sub_lazy<C, 4>(A0, A1), wb), p01);
+                st_fr_weak<S>(fe_add_lazy<C>(B0, B1), p10);
+                st_fr_weak<S>(fe_mul<C>(fe_sub_lazy<C, 2>(B0, B1), wb), p11);
             } else {
                 // stage s1 pairs over the LOW bit, one twiddle; stage s1-1 pairs over the HIGH bit, twiddle depends on the low bit
-                const Fr w1 = ld_fr(tab1 + (size_t)((low << Lb) | inner) * 8);
-                const Fr w20 = ld_fr(tab2 + (size_t)((low << Lb) | inner) * 8);
-                const Fr w21 = ld_fr(tab2 + (size_t)((((1u << dlo) | low) << Lb) | inner) * 8);
+                const Fr w1 = ld_fr<S>(tab1 + (size_t)((low << Lb) | inner) * 8);
+                const Fr w20 = ld_fr<S>(tab2 + (size_t)((low << Lb) | inner) * 8);
+                const Fr w21 = ld_fr<S>(tab2 + (size_t)((((1u << dlo) | low) << Lb) | inner) * 8);
                 const Fr t0 = fe_mul<C>(x01, w1), t1 = fe_mul<C>(x11, w1);
                 const Fr a00 = fe_add_lazy<C>(x00, t0), a01 = fe_sub_lazy<C, 2>(x00, t0);     // < 5.1p, < 6p
                 const Fr a10 = fe_add_lazy<C>(x10, t1), a11 = fe_sub_lazy<C, 2>(x10, t1);
                 const Fr u0 = fe_mul<C>(a10, w20), u1 = fe_mul<C>(a11, w21);
-                st_fr_weak(fe_csub<C, 4>(fe_add_lazy<C>(a00, u0)), p00);
-                st_fr_weak(fe_csub<C, 4>(fe_add_lazy<C>(a01, u1)), p01);
-                st_fr_weak(fe_csub<C, 4>(fe_sub_lazy<C, 2>(a00, u0)), p10);
-                st_fr_weak(fe_csub<C, 4>(fe_sub_lazy<C, 2>(a01, u1)), p11);
+                st_fr_weak<S>(fe_csub<C, 4>(fe_add_lazy<C>(a00, u0)), p00);
+                st_fr_weak<S>(fe_csub<C, 4>(fe_add_lazy<C>(a01, u1)), p01);
+                st_fr_weak<S>(fe_csub<C, 4>(fe_sub_lazy<C, 2>(a00, u0)), p10);
+                st_fr_weak<S>(fe_csub<C, 4>(fe_sub_lazy<C, 2>(a01, u1)), p11);
             }
         }
         __syncthreads();
@@ -151,17 +152,17 @@ static __global__ __launch_bounds__(512) void k_ntt_pass(u32* __restrict__ data,
             const u32 low = dp & (dist - 1);
             const u32 D0 = ((dp >> dshift) << (dshift + 1)) | low, D1 = D0 | dist;
             const u32 j = (low << Lb) | ((sp0 + q) & inner_mask);
-            const Fr w = ld_fr(table + (size_t)j * 8);
+            const Fr w = ld_fr<S>(table + (size_t)j * 8);
             u32* pa = lds + (size_t)((D0 << log_i) | q) * 8;
             u32* pb = lds + (size_t)((D1 << log_i) | q) * 8;
-            const Fr a = ld_fr(pa), b = ld_fr(pb);
+            const Fr a = ld_fr<S>(pa), b = ld_fr<S>(pb);
             if (!dit) {
-                st_fr_weak(fe_csub<C, 4>(fe_add_lazy<C>(a, b)), pa);
-                st_fr_weak(fe_mul<C>(fe_sub_lazy<C, 4>(a, b), w), pb);
+                st_fr_weak<S>(fe_csub<C, 4>(fe_add_lazy<C>(a, b)), pa);
+                st_fr_weak<S>(fe_mul<C>(fe_sub_lazy<C, 4>(a, b), w), pb);
             } else {
                 const Fr bt = fe_mul<C>(b, w);
-                st_fr_weak(fe_csub<C, 4>(fe_add_lazy<C>(a, bt)), pa);
-                st_fr_weak(fe_csub<C, 4>(fe_sub_lazy<C, 2>(a, bt)), pb);
+                st_fr_weak<S>(fe_csub<C, 4>(fe_add_lazy<C>(a, bt)), pa);
+                st_fr_weak<S>(fe_csub<C, 4>(fe_sub_lazy<C, 2>(a, bt)), pb);
             }
         }
         __syncthreads();
@@ -170,22 +171,22 @@ static __global__ __launch_bounds__(512) void k_ntt_pass(u32* __restrict__ data,
     for (u32 le = threadIdx.x; le < E; le += blockDim.x) {
         const u32 q = le & (I - 1), D = le >> log_i, sp = sp0 + q;
         const u32 gi = ((sp >> Lb) << (Lb + K)) | (D << Lb) | (sp & inner_mask);
-        Fr v = ld_fr(lds + (size_t)le * 8);
-        if (sc.mode && sc.when == 2) st_fr(fe_mul<C>(v, ntt_scale_factor(sc, gi, log_n)), data + (size_t)gi * 8);
-        else st_fr4(v, data + (size_t)gi * 8);
+        Fr v = ld_fr<S>(lds + (size_t)le * 8);
+        if (sc.mode && sc.when == 2) st_fr<S>(fe_mul<C>(v, ntt_scale_factor<S>(sc, gi, log_n)), data + (size_t)gi * 8);
+        else st_fr4<S>(v, data + (size_t)gi * 8);
     }
 }
 
 // computeH pointwise step: a[i] = (a[i] * b[i] - c[i]) * den   (all words external Montgomery)
 // k1 = internal form of den * 2^5, k2 = internal form of den (see bn254_field.h on the 2^-5 reading)
-static __global__ void k_h_pointwise(u32* __restrict__ a, const u32* __restrict__ b, const u32* __restrict__ c,
+template <class S> __global__ void k_h_pointwise(u32* __restrict__ a, const u32* __restrict__ b, const u32* __restrict__ c,
                               const u32* __restrict__ k1k2, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const Fr k1 = ld_fr(k1k2), k2 = ld_fr(k1k2 + 8);
-    Fr ab = fe_mul<FrCfg>(fe_mul<FrCfg>(ld_fr(a + i * 8), ld_fr(b + i * 8)), k1);
-    Fr cd = fe_mul<FrCfg>(ld_fr(c + i * 8), k2);
-    st_fr(fe_sub<FrCfg>(ab, cd), a + i * 8);
+    const Fe<S> k1 = ld_fr<S>(k1k2), k2 = ld_fr<S>(k1k2 + 8);
+    Fe<S> ab = fe_mul<S>(fe_mul<S>(ld_fr<S>(a + i * 8), ld_fr<S>(b + i * 8)), k1);
+    Fe<S> cd = fe_mul<S>(ld_fr<S>(c + i * 8), k2);
+    st_fr<S>(fe_sub<S>(ab, cd), a + i * 8);
 }
 
 }  // namespace dvn

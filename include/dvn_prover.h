@@ -194,6 +194,25 @@ int32_t dvn_prover_prove(dvn_ctx* ctx, int32_t curve, const dvn_r1cs* ccs, dvn_g
                          const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32]);
 int32_t dvn_prover_setup(dvn_ctx* ctx, const dvn_r1cs* ccs, uint64_t seed, dvn_groth16_pk** pk);   /* prover.Setup */
 
+/* ---- BLS12-377 ------------------------------------------------------------------------------------ */
+/* The voteverifier's curve (/root/reference/spec/params/params.go:21-27; reference GPU dispatch prover/prover_gpu.go:36-43).
+ * Same kernels, instantiated on 377-bit base-field elements.  gnark images: fp.Element 6 x uint64 (R = 2^384),
+ * fr.Element 4 x uint64, G1Affine 12 x uint64, G2Affine 24 x uint64 (E2 = A0 + A1 u, u^2 = -5), G1Jac 18, G2Jac 36.
+ * Handles are the same dvn_points / dvn_domain types (they remember their curve; mixing curves is rejected);
+ * dvn_points_len / dvn_points_free / dvn_ntt_domain_free apply to them as well. */
+int32_t dvn_bls12377_points_upload_g1(dvn_ctx* ctx, const uint64_t* xy_mont /* n x 12 */, size_t n, dvn_points** out);
+int32_t dvn_bls12377_points_upload_g2(dvn_ctx* ctx, const uint64_t* xy_mont /* n x 24 */, size_t n, dvn_points** out);
+int32_t dvn_bls12377_points_synthetic_g1(dvn_ctx* ctx, uint64_t seed, size_t n, dvn_points** out);
+int32_t dvn_bls12377_points_download(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, uint64_t* xy_mont);
+int32_t dvn_bls12377_scalars_synthetic(dvn_ctx* ctx, uint64_t seed, int kind, size_t n, void* d_out);
+int32_t dvn_bls12377_msm_g1(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars_mont,
+                            uint32_t flags, uint64_t out_jac[18]);
+int32_t dvn_bls12377_msm_g2(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars_mont,
+                            uint32_t flags, uint64_t out_jac[36]);
+int32_t dvn_bls12377_ntt_domain(dvn_ctx* ctx, uint32_t log_n, dvn_domain** out);      /* log_n <= 27 (two-adicity 47) */
+int32_t dvn_bls12377_ntt(dvn_ctx* ctx, const dvn_domain* dom, uint64_t* data, int inverse, int decimation, int on_coset,
+                         uint32_t flags);
+
 /* ---- timing of the last call's kernels, measured with HIP events on the library's own stream ---------- */
 /* which: 0 = whole device section of the last MSM/NTT call, 1 = its dominant kernel (MSM: bucket
  * accumulation; NTT: sum of butterfly passes). */
