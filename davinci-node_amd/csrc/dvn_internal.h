@@ -33,7 +33,7 @@ struct MsmLane {
     float ms[2] = {0.f, 0.f};
 };
 constexpr int DVN_LANES = 2;
-constexpr size_t DVN_HSUMS_WORDS = 64 * 64;     // up to 64 windows of a G2 xyzz image
+constexpr size_t DVN_HSUMS_WORDS = 64 * 128;    // up to 64 windows of the widest xyzz image (BLS12-377 G2: 96 words)
 
 struct dvn_ctx {
     int device = 0;
