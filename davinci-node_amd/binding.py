@@ -99,6 +99,11 @@ def load_library():
         "dvn_bls12377_msm_g2": (i32, [vp, vp, sz, sz, vp, u32, vp]),
         "dvn_bls12377_ntt_domain": (i32, [vp, u32, C.POINTER(vp)]),
         "dvn_bls12377_ntt": (i32, [vp, vp, vp, C.c_int, C.c_int, C.c_int, u32]),
+        "dvn_bw6761_points_upload": (i32, [vp, C.c_int, vp, sz, C.POINTER(vp)]),
+        "dvn_bw6761_points_synthetic": (i32, [vp, C.c_int, vp, u64, sz, C.POINTER(vp)]),
+        "dvn_bw6761_points_download": (i32, [vp, vp, sz, sz, vp]),
+        "dvn_bw6761_scalars_synthetic": (i32, [vp, u64, C.c_int, sz, vp]),
+        "dvn_bw6761_msm": (i32, [vp, vp, sz, sz, vp, u32, vp]),
         "dvn_prover_use_gpu": (i32, []),
         "dvn_prover_set_use_gpu": (None, [i32]),
         "dvn_prover_reload_env": (None, []),
@@ -126,6 +131,7 @@ EXPORTED_SYMBOLS = [
     "dvn_groth16_proof_abi_encode", "dvn_pedersen_commit",
     "dvn_bls12377_points_upload_g1", "dvn_bls12377_points_upload_g2", "dvn_bls12377_points_synthetic_g1", "dvn_bls12377_points_download",
     "dvn_bls12377_scalars_synthetic", "dvn_bls12377_msm_g1", "dvn_bls12377_msm_g2", "dvn_bls12377_ntt_domain", "dvn_bls12377_ntt",
+    "dvn_bw6761_points_upload", "dvn_bw6761_points_synthetic", "dvn_bw6761_points_download", "dvn_bw6761_scalars_synthetic", "dvn_bw6761_msm",
     "dvn_prover_use_gpu", "dvn_prover_set_use_gpu", "dvn_prover_reload_env", "dvn_prover_set_prover", "dvn_prover_set_cpu_backend",
     "dvn_prover_last_backend", "dvn_prover_prove", "dvn_prover_setup",
 ]
@@ -465,3 +471,43 @@ class Bls12377:
         assert data.dtype == np.uint64 and data.flags["C_CONTIGUOUS"] and data.shape == (dom.n, 4)
         self.ctx._chk(self.L.dvn_bls12377_ntt(self.ctx.h, dom.handle, _host(data), int(inverse), decimation, int(coset), 0))
         return data
+
+
+class Bw6761:
+    """BW6-761 MSM entry points over an existing Context.  Points: (n,24) uint64 for either
+    group; scalars (n,6) uint64."""
+
+    def __init__(self, ctx: Context):
+        self.ctx, self.L = ctx, ctx.L
+
+    def upload(self, group: int, xy: np.ndarray) -> Points:
+        assert xy.dtype == np.uint64 and xy.ndim == 2 and xy.shape[1] == 24 and xy.flags["C_CONTIGUOUS"]
+        p = C.c_void_p(); self.ctx._chk(self.L.dvn_bw6761_points_upload(self.ctx.h, group, _host(xy), xy.shape[0], C.byref(p)))
+        return Points(self.ctx, p, group)
+
+    def synthetic(self, group: int, base_xy: np.ndarray, seed: int, n: int) -> Points:
+        base_xy = np.ascontiguousarray(base_xy, dtype=np.uint64).reshape(24)
+        p = C.c_void_p(); self.ctx._chk(self.L.dvn_bw6761_points_synthetic(self.ctx.h, group, _host(base_xy), seed, n, C.byref(p)))
+        return Points(self.ctx, p, group)
+
+    def download(self, pts: Points, off: int = 0, n: int | None = None) -> np.ndarray:
+        n = len(pts) - off if n is None else n
+        out = np.zeros((n, 24), dtype=np.uint64)
+        self.ctx._chk(self.L.dvn_bw6761_points_download(self.ctx.h, pts.handle, off, n, _host(out)))
+        return out
+
+    def synthetic_scalars(self, seed: int, kind: int, n: int) -> int:
+        d = self.ctx.malloc(n * 48)
+        self.ctx._chk(self.L.dvn_bw6761_scalars_synthetic(self.ctx.h, seed, kind, n, C.c_void_p(d)))
+        return d
+
+    def msm(self, pts: Points, scalars, off: int = 0, n: int | None = None) -> np.ndarray:
+        if isinstance(scalars, (int, np.integer)):
+            assert n is not None
+            sp, ns, fl = C.c_void_p(int(scalars)), n, MSM_SCALARS_ON_DEVICE
+        else:
+            scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 6)
+            sp, ns, fl = _host(scalars), scalars.shape[0], 0
+        out = np.zeros(36, dtype=np.uint64)
+        self.ctx._chk(self.L.dvn_bw6761_msm(self.ctx.h, pts.handle, off, ns, sp, fl, _host(out)))
+        return out

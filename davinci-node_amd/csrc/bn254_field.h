@@ -353,9 +353,12 @@ typedef Fe2<FpCfg> Fp2;
 typedef Fe<Fp377Cfg> Fp377;
 typedef Fe<Fr377Cfg> Fr377;
 typedef Fe2<Fp377Cfg> Fp2_377;
+typedef Fe<Fp761Cfg> Fp761;
 
 // Uniform "field ops" interface used by the curve templates
 template <class F> struct Ops;
+template <class C> static DVN_NOINLINE Fe<C> fp_mul_call(Fe<C> a, Fe<C> b);
+template <class C> static DVN_NOINLINE Fe<C> fp_sqr_call(Fe<C> a);
 template <class C> struct Ops<Fe<C>> {
     typedef Fe<C> F;
     typedef C Cfg;
@@ -365,8 +368,10 @@ template <class C> struct Ops<Fe<C>> {
     static DVN_HD F sub(const F& a, const F& b) { return fe_sub<C>(a, b); }
     static DVN_HD F dbl(const F& a) { return fe_dbl<C>(a); }
     static DVN_HD F neg(const F& a) { return fe_neg<C>(a); }
-    static DVN_HD F mul(const F& a, const F& b) { return fe_mul<C>(a, b); }
-    static DVN_HD F sqr(const F& a) { return fe_sqr<C>(a); }
+    // wide fields (BW6-761: 27 limbs, 108 registers of column accumulators): the multiplication is a real call
+    static constexpr bool CALL_MUL = C::NL > 16;
+    static DVN_HD F mul(const F& a, const F& b) { if constexpr (CALL_MUL) return fp_mul_call<C>(a, b); else return fe_mul<C>(a, b); }
+    static DVN_HD F sqr(const F& a) { if constexpr (CALL_MUL) return fp_sqr_call<C>(a); else return fe_sqr<C>(a); }
     static DVN_HD F inv(const F& a) { return fe_inv<C>(a); }
     static DVN_HD bool is_zero(const F& a) { return fe_is_zero<C>(a); }
     static DVN_HD bool is_literal_zero(const F& a) { u32 z = 0;
@@ -375,7 +380,9 @@ template <class C> struct Ops<Fe<C>> {
         return z == 0; }
     static constexpr int WORDS = C::EW;   // external u32 words per element
     static constexpr bool OUTLINE = false;
-    static constexpr bool LAZY = true;    // Curve::acc_add_mixed uses the lazily reduced formulas
+    // Curve::acc_add_mixed uses the lazily reduced formulas where the 64-bit column accumulators have the headroom:
+    // 3 x NL products of < 2^58 (+ limbs up to 2^30) must stay below 2^64 -> NL <= 16
+    static constexpr bool LAZY = C::NL <= 16;
     static DVN_HD F load_internal(const u32* w) { u32 t[C::EW];
 #pragma unroll
         for (int i = 0; i < C::EW; ++i) t[i] = w[i];

@@ -135,3 +135,36 @@ void hc377_g1_acc_chain(const uint32_t* pts, const uint32_t* idx, size_t n, uint
     G1_377::affine_to_ext(G1_377::to_affine(G1_377::acc_normalize(acc)), out);
 }
 }
+
+// ---- BW6-761 (27 x 29-bit limbs, external 12 x u64; scalars 377 bits = 12 words) ----------------------------------------
+template <class Cv, int KW> static void msm_naive_wide(const uint32_t* pts, const uint32_t* k, size_t n, uint32_t* out) {
+    typename Cv::X acc = Cv::infinity();
+    for (size_t i = 0; i < n; ++i) {
+        typename Cv::A p = Cv::affine_from_ext(pts + (size_t)Cv::AW * i);
+        typename Cv::X t = Cv::infinity();
+        for (int b = 32 * KW - 1; b >= 0; --b) {
+            t = Cv::dbl(t);
+            if ((k[KW * i + (b >> 5)] >> (b & 31)) & 1) t = Cv::add_mixed(t, p);
+        }
+        acc = Cv::add(acc, t);
+    }
+    Cv::affine_to_ext(Cv::to_affine(acc), out);
+}
+extern "C" {
+void hc761_fp_op(const uint32_t* a, const uint32_t* b, uint32_t* r, int op) { bin12<Fp761Cfg>(a, b, r, op); }
+// the scalar path of the MSM: gnark Montgomery image (R = 2^384) of a BLS12-377 Fp element -> canonical words
+void hc761_scalar_ext_to_canonical(const uint32_t* a, uint32_t* r) {
+    u32 wa[12], wr[12]; memcpy(wa, a, 48);
+    fe_pack<Fp377Cfg>(fe_ext_mont_to_canonical<Fp377Cfg>(wa), wr); memcpy(r, wr, 48);
+}
+void hc761_msm_naive(const uint32_t* pts, const uint32_t* k, size_t n, uint32_t* out) { msm_naive_wide<G_761, 12>(pts, k, n, out); }
+void hc761_acc_chain(const uint32_t* pts, const uint32_t* idx, size_t n, uint32_t* out) {
+    G_761::X acc = G_761::infinity();
+    for (size_t i = 0; i < n; ++i) {
+        G_761::A p = G_761::affine_from_ext(pts + (size_t)G_761::AW * (idx[i] & 0x7fffffffu));
+        if (idx[i] & 0x80000000u) p = G_761::neg(p);
+        acc = G_761::acc_add_mixed(acc, p);
+    }
+    G_761::affine_to_ext(G_761::to_affine(G_761::acc_normalize(acc)), out);
+}
+}

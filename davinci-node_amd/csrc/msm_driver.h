@@ -14,6 +14,12 @@ template <> struct ScalarOf<G2_377> { typedef Fr377Cfg S; };
 template <class Cv> struct SuiteOf { static constexpr int value = 0; };          // 0 = BN254, 1 = BLS12-377
 template <> struct SuiteOf<G1_377> { static constexpr int value = 1; };
 template <> struct SuiteOf<G2_377> { static constexpr int value = 1; };
+template <> struct ScalarOf<G_761> { typedef Fp377Cfg S; };                          // BW6-761's scalar field is BLS12-377's base field
+template <> struct SuiteOf<G_761> { static constexpr int value = 2; };               // 2 = BW6-761
+template <class F> struct IsQuadratic { static constexpr bool value = false; };
+template <class C> struct IsQuadratic<Fe2<C>> { static constexpr bool value = true; };
+// expanded point sets are planned for G2 over a quadratic extension only (BW6-761's G2 lives over the base field)
+template <class Cv> static inline int plan_curve(int curve) { return (curve == 2 && !IsQuadratic<typename Cv::O::F>::value) ? 1 : curve; }
 
 // ------------------------------------------------------------------------------------------------------
 // points
@@ -27,7 +33,7 @@ template <class Cv> static int32_t points_upload(dvn_ctx* ctx, const uint64_t* x
     if (!p) return fail(DVN_ERR_OOM, "host allocation failed");
     p->curve = curve; p->n = n;
     p->suite = SuiteOf<Cv>::value;
-    expand_plan(curve, n, ScalarOf<Cv>::S::BITS, &p->expand_c, &p->nexp);
+    expand_plan(plan_curve<Cv>(curve), n, ScalarOf<Cv>::S::BITS, &p->expand_c, &p->nexp);
     size_t bytes = n * Cv::AW * 4;
     hipError_t e = hipMalloc((void**)&p->d, bytes ? bytes * p->nexp : 16);
     if (e != hipSuccess) { delete p; (void)hipGetLastError(); return fail(DVN_ERR_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
@@ -45,6 +51,33 @@ template <class Cv> static int32_t points_upload(dvn_ctx* ctx, const uint64_t* x
     return DVN_OK;
 }
 
+// P_i = base + i*step on the device (bench/test input generator; caller holds ctx->mu)
+template <class Cv> static int32_t points_progression(dvn_ctx* ctx, size_t n, int curve, const typename Cv::A& base, const typename Cv::A& step, dvn_points** out) {
+    u32 hb[2 * Cv::AW];
+    Cv::store_affine_internal(base, hb); Cv::store_affine_internal(step, hb + Cv::AW);
+    dvn_points* p = new (std::nothrow) dvn_points();
+    if (!p) return fail(DVN_ERR_OOM, "host allocation failed");
+    p->curve = curve; p->n = n;
+    p->suite = SuiteOf<Cv>::value;
+    expand_plan(plan_curve<Cv>(curve), n, ScalarOf<Cv>::S::BITS, &p->expand_c, &p->nexp);
+    u32* dbs = nullptr;
+    hipError_t e = hipMalloc((void**)&p->d, n ? n * Cv::AW * 4 * p->nexp : 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&dbs, sizeof(hb));
+    if (e == hipSuccess) e = hipMemcpyAsync(dbs, hb, sizeof(hb), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && n) {
+        const u32 chunk = 16;
+        size_t threads = (n + chunk - 1) / chunk;
+        k_points_progression<Cv><<<(unsigned)((threads + 63) / 64), 64, 0, ctx->stream>>>(p->d, n, dbs, chunk);
+        if (p->expand_c) k_points_expand<Cv><<<(unsigned)((n + 63) / 64), 64, 0, ctx->stream>>>(p->d, n, p->expand_c, p->nexp);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (dbs) (void)hipFree(dbs);
+    if (e != hipSuccess) { if (p->d) (void)hipFree(p->d); delete p; (void)hipGetLastError(); return fail(DVN_ERR_DEVICE, "synthetic points failed: %s", hipGetErrorString(e)); }
+    *out = p;
+    return DVN_OK;
+}
+
 template <class Cv> static int32_t points_synthetic(dvn_ctx* ctx, uint64_t seed, size_t n, int curve, const typename Cv::A& gen, dvn_points** out) {
     TRY(enter(ctx));
     if (!out) return fail(DVN_ERR_INVALID_ARG, "out is NULL");
@@ -58,7 +91,7 @@ template <class Cv> static int32_t points_synthetic(dvn_ctx* ctx, uint64_t seed,
     if (!p) return fail(DVN_ERR_OOM, "host allocation failed");
     p->curve = curve; p->n = n;
     p->suite = SuiteOf<Cv>::value;
-    expand_plan(curve, n, ScalarOf<Cv>::S::BITS, &p->expand_c, &p->nexp);
+    expand_plan(plan_curve<Cv>(curve), n, ScalarOf<Cv>::S::BITS, &p->expand_c, &p->nexp);
     u32* dbs = nullptr;
     hipError_t e = hipMalloc((void**)&p->d, n ? n * Cv::AW * 4 * p->nexp : 16);
     if (e == hipSuccess) e = hipMalloc((void**)&dbs, sizeof(hb));
@@ -141,7 +174,8 @@ static int32_t msm_windows(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, size
     const u32 tile_len = 65536;
     const u32 ntiles = (u32)((n + tile_len - 1) / tile_len);
     CarverSize cs;
-    if (!on_dev) cs.take(n * 32);
+    constexpr size_t SB = ScalarOf<Cv>::S::EW * 4;       // bytes per scalar
+    if (!on_dev) cs.take(n * SB);
     cs.take((size_t)W * n * 2); cs.take((size_t)W * n * 4);          // digits (int16), sorted
     cs.take((size_t)W * ntiles * nb * 4);                             // per-tile histograms
     cs.take((size_t)W * nb * 4 * 2); cs.take((size_t)W * 4 + 4);      // counts, offsets; totals + heavy_count
@@ -153,8 +187,8 @@ static int32_t msm_windows(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, size
     Carver cv(L.ws);
     const u32* d_scalars;
     if (!on_dev) {
-        u32* tmp = cv.take<u32>(n * 8);
-        HIP_TRY(hipMemcpy(tmp, scalars, n * 32, hipMemcpyHostToDevice));   // caller's buffer is free on return (cgo rule)
+        u32* tmp = cv.take<u32>(n * (SB / 4));
+        HIP_TRY(hipMemcpy(tmp, scalars, n * SB, hipMemcpyHostToDevice));   // caller's buffer is free on return (cgo rule)
         d_scalars = tmp;
     } else d_scalars = (const u32*)scalars;
     int16_t* digits = cv.take<int16_t>((size_t)W * n);
@@ -241,7 +275,8 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
     const bool on_dev = flags & DVN_MSM_SCALARS_ON_DEVICE;
 
     CarverSize cs;
-    if (!on_dev) cs.take(n * 32);
+    constexpr size_t SB = ScalarOf<Cv>::S::EW * 4;       // bytes per scalar
+    if (!on_dev) cs.take(n * SB);
     cs.take(total * 4); cs.take(total * 4); cs.take(total * 2); cs.take(total * 4);    // digits, p1_ref, p1_lo, sorted
     cs.take((size_t)ntiles * hb * 4); cs.take((size_t)(2 * hb + 2) * 4);                 // hist1; bin_total, bin_base
     cs.take((size_t)nb * 4 * 2); cs.take(16);                                            // counts, offsets; totals + heavy_count
@@ -253,8 +288,8 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
     Carver cv(L.ws);
     const u32* d_scalars;
     if (!on_dev) {
-        u32* tmp = cv.take<u32>(n * 8);
-        HIP_TRY(hipMemcpy(tmp, scalars, n * 32, hipMemcpyHostToDevice));   // caller's buffer is free on return (cgo rule)
+        u32* tmp = cv.take<u32>(n * (SB / 4));
+        HIP_TRY(hipMemcpy(tmp, scalars, n * SB, hipMemcpyHostToDevice));   // caller's buffer is free on return (cgo rule)
         d_scalars = tmp;
     } else d_scalars = (const u32*)scalars;
     int* digits = cv.take<int>(total);

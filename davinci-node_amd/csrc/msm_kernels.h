@@ -102,38 +102,40 @@ __device__ __forceinline__ u64 dev_splitmix_at(u64 seed, u64 index) {
 }
 // kind 0: uniform mod r; kind 1: 40 % zero, 25 % one, 25 % < 2^64, 10 % uniform.  Output gnark Montgomery words.
 template <class S> __global__ void k_scalars_synthetic(u32* __restrict__ out, size_t n, u64 seed, int kind) {
-    static_assert(S::EW == 8, "scalar fields are 4 x u64");
+    constexpr int EW = S::EW, QW = S::EW / 2;          // external u32 words, 64-bit stream words per scalar
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    u32 w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u32 w[EW];
+#pragma unroll
+    for (int j = 0; j < EW; ++j) w[j] = 0;
     int mode = 3;   // 0 zero, 1 one, 2 one word, 3 full
     if (kind == 1) {
         const u64 sel = dev_splitmix_at(seed ^ 0x5EED5EED5EED5EEDULL, i) % 100;
         mode = sel < 40 ? 0 : sel < 65 ? 1 : sel < 90 ? 2 : 3;
     }
     if (mode == 1) w[0] = 1;
-    else if (mode == 2) { u64 v = dev_splitmix_at(seed, 4 * i); w[0] = (u32)v; w[1] = (u32)(v >> 32); }
+    else if (mode == 2) { u64 v = dev_splitmix_at(seed, QW * i); w[0] = (u32)v; w[1] = (u32)(v >> 32); }
     else if (mode == 3) {
-        for (int k = 0; k < 4; ++k) { u64 v = dev_splitmix_at(seed, 4 * i + k); w[2 * k] = (u32)v; w[2 * k + 1] = (u32)(v >> 32); }
-        // reduce the 256-bit value mod r (< 6r): repeated conditional subtraction
-        u32 rm[8];
-        { u32 t[8]; Fe<S> pm;
+        for (int k = 0; k < QW; ++k) { u64 v = dev_splitmix_at(seed, QW * i + k); w[2 * k] = (u32)v; w[2 * k + 1] = (u32)(v >> 32); }
+        // reduce the 32*EW-bit value mod the field order: repeated conditional subtraction
+        u32 rm[EW];
+        { u32 t[EW]; Fe<S> pm;
 #pragma unroll
           for (int j = 0; j < S::NL; ++j) pm.v[j] = S::p(j);
           fe_pack<S>(pm, t);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) rm[j] = t[j]; }
-        for (int rep = 0; rep < 16; ++rep) {
+          for (int j = 0; j < EW; ++j) rm[j] = t[j]; }
+        for (int rep = 0; rep < 256; ++rep) {
             bool ge = true;
-            for (int j = 7; j >= 0; --j) { if (w[j] > rm[j]) { ge = true; break; } if (w[j] < rm[j]) { ge = false; break; } }
+            for (int j = EW - 1; j >= 0; --j) { if (w[j] > rm[j]) { ge = true; break; } if (w[j] < rm[j]) { ge = false; break; } }
             if (!ge) break;
             u64 br = 0;
-            for (int j = 0; j < 8; ++j) { u64 d = (u64)w[j] - rm[j] - br; w[j] = (u32)d; br = (d >> 32) & 1; }
+            for (int j = 0; j < EW; ++j) { u64 d = (u64)w[j] - rm[j] - br; w[j] = (u32)d; br = (d >> 32) & 1; }
         }
     }
-    u32 o[8];
+    u32 o[EW];
     fe_to_ext_mont<S>(fe_from_canonical<S>(fe_unpack<S>(w)), o);
-    store_words16(out + i * 8, o, 8);
+    store_words16(out + i * EW, o, EW);
 }
 
 // ---- digits -> per-window counting sort, all ranking done with LDS atomics (no global atomics) ------------------
@@ -141,24 +143,25 @@ template <class S> __global__ void k_scalars_synthetic(u32* __restrict__ out, si
 // Bucket index of a non-zero digit d is |d| - 1 in [0, 2^(c-1)).
 template <class S> __global__ void k_digits16(const u32* __restrict__ scalars, size_t n, u32 c, u32 win_lo, u32 win_hi,
                                   int16_t* __restrict__ digits) {
+    constexpr int EW = S::EW;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    u32 w[8];
-    load_words16(scalars + i * 8, w, 8);
+    u32 w[EW];
+    load_words16(scalars + i * EW, w, EW);
     Fe<S> k = fe_ext_mont_to_canonical<S>(w);
-    u32 kw[9];
+    u32 kw[EW + 1];
     {
-        u32 t[8]; fe_pack<S>(k, t);
+        u32 t[EW]; fe_pack<S>(k, t);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) kw[j] = t[j];
-        kw[8] = 0;
+        for (int j = 0; j < EW; ++j) kw[j] = t[j];
+        kw[EW] = 0;
     }
     const u32 nb = 1u << (c - 1), mask = (1u << c) - 1;
     u32 carry = 0;
     for (u32 win = 0; win < win_hi; ++win) {
         const u32 bit = win * c;
         u32 d = carry;
-        if (bit < 256) {
+        if (bit < 32 * EW) {
             const u32 wi = bit >> 5, sh = bit & 31;
             u64 two = (u64)kw[wi] | ((u64)kw[wi + 1] << 32);
             d += (u32)(two >> sh) & mask;
@@ -265,24 +268,25 @@ template <class Cv> __global__ void k_points_expand(u32* __restrict__ table, siz
 }
 // signed c-bit digits (c <= 24) as int32: digits[(w - win_lo) * n + i] in [-2^(c-1), 2^(c-1) - 1]
 template <class S> __global__ void k_digits32(const u32* __restrict__ scalars, size_t n, u32 c, u32 win_lo, u32 win_hi, int* __restrict__ digits) {
+    constexpr int EW = S::EW;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    u32 w[8];
-    load_words16(scalars + i * 8, w, 8);
+    u32 w[EW];
+    load_words16(scalars + i * EW, w, EW);
     Fe<S> k = fe_ext_mont_to_canonical<S>(w);
-    u32 kw[9];
+    u32 kw[EW + 1];
     {
-        u32 t[8]; fe_pack<S>(k, t);
+        u32 t[EW]; fe_pack<S>(k, t);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) kw[j] = t[j];
-        kw[8] = 0;
+        for (int j = 0; j < EW; ++j) kw[j] = t[j];
+        kw[EW] = 0;
     }
     const u32 nb = 1u << (c - 1), mask = (1u << c) - 1;
     u32 carry = 0;
     for (u32 win = 0; win < win_hi; ++win) {
         const u32 bit = win * c;
         u32 d = carry;
-        if (bit < 256) {
+        if (bit < 32 * EW) {
             const u32 wi = bit >> 5, sh = bit & 31;
             u64 two = (u64)kw[wi] | ((u64)kw[wi + 1] << 32);
             d += (u32)(two >> sh) & mask;

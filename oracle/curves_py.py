@@ -6,6 +6,8 @@ Same conventions as gnark-crypto: Element = little-endian u64 limbs in Montgomer
 (4 limbs for the 253/254-bit fields, 6 for BLS12-377's 377-bit base field); E2 = a0 + a1*u with u^2 = -BETA;
 affine infinity = all-zero image; fft.Domain DIF/DIT/coset semantics with the curve's multiplicative generator.
 
+BW6-761 (aggregator, params.go:24) is the `Bw6761` class at the bottom: both groups over the 761-bit base field.
+
 PARITY UNPINNED: no vectors for these primitives exist in the reference.  The constants below were cross-checked here:
 r | #E(Fp) via r*G1 = O, G1 on y^2 = x^3 + 1, root_of_unity == gen^((r-1)/2^47) == gnark-crypto's hard-coded
 8065159656716812877374967518403273466521432693661810619979959746626482506078, twist coefficient == 1/u = (0, -1/5).
@@ -254,3 +256,82 @@ BLS12_377 = Suite(
             0x01914A69C5102EFF1F674F5D30AFEEC4BD7FB348CA3E52D96D182AD44FB82305C2FE3D3634A9591AFD82DE55559C8EA6),
     fr_gen=22, two_adicity=47)
 BN254 = Suite("bn254", b.P, b.R, b_g1=3, beta=1, b_g2=b.B_G2, g1_gen=b.G1_GEN, fr_gen=5, two_adicity=28)
+
+
+class Bw6761:
+    """BW6-761 (gnark-crypto ecc/bw6-761): G1: y^2 = x^3 - 1 and G2: y^2 = x^3 + 4, both over the 761-bit base field;
+    the scalar field is BLS12-377's base field (377 bits).  Element images: 12 x u64 (R = 2^768) for coordinates,
+    6 x u64 (R = 2^384) for scalars.  Constants cross-checked in tests/test_bw6761.py (primality, embedding degree 6,
+    p = 3 mod 4, r | #E for both curves through cofactor-cleared points)."""
+    p = 0x122E824FB83CE0AD187C94004FAFF3EB926186A81D14688528275EF8087BE41707BA638E584E91903CEBAFF25B423048689C8ED12F9FD9071DCD3DC73EBFF2E98A116C25667A8F8160CF8AEEAF0A437E6913E6870000082F49D00000000008B
+    r = _P377
+    fp_limbs, fr_limbs = 12, 6
+    name = "bw6-761"
+
+    def __init__(self):
+        self.fp = PrimeField(self.p)
+        self.b = {1: self.p - 1, 2: 4}
+
+    def fp_to_mont(self, x): return (x << 768) % self.p
+    def fr_to_mont(self, x): return (x << 384) % self.r
+    def fr_from_mont(self, x): return x * pow(1 << 384, -1, self.r) % self.r
+    def limbs(self, x, n): return [(x >> (64 * i)) & MASK64 for i in range(n)]
+    def to_limbs(self, pt):
+        if pt is None:
+            return [0] * 24
+        return self.limbs(self.fp_to_mont(pt[0]), 12) + self.limbs(self.fp_to_mont(pt[1]), 12)
+    def fr_to_limbs(self, x): return self.limbs(self.fr_to_mont(x), 6)
+    def fr_from_limbs(self, ls): return self.fr_from_mont(b.from_limbs(ls))
+
+    def on_curve(self, group, pt): return b.ec_is_on_curve(self.fp, self.b[group], pt)
+    def add(self, a, c): return b.ec_add(self.fp, a, c)
+    def neg(self, a): return b.ec_neg(self.fp, a)
+    def mul(self, a, k): return b.ec_mul(self.fp, a, k)
+
+    def some_point(self, group, start=2):
+        """Smallest x >= start with x^3 + b a square (p = 3 mod 4: sqrt = a^((p+1)/4)); NOT cofactor-cleared: the
+        group law and the MSM (integer scalars) do not need the r-torsion."""
+        x = start
+        while True:
+            rhs = (x * x * x + self.b[group]) % self.p
+            y = pow(rhs, (self.p + 1) // 4, self.p)
+            if y * y % self.p == rhs:
+                return (x, min(y, self.p - y))
+            x += 1
+
+    def msm(self, pts, ks):
+        """Integer-scalar MSM (no reduction mod r: the points need not lie in the r-torsion)."""
+        if len(pts) != len(ks):
+            raise ValueError("len(points) != len(scalars)")
+        acc = None
+        for pt, k in zip(pts, ks):
+            acc = b.ec_add(self.fp, acc, b.ec_mul(self.fp, pt, k))
+        return acc
+
+    def fr_at(self, seed, i):
+        """i-th canonical scalar of SplitMix64 stream `seed`: the 384-bit value of six stream words, mod r."""
+        v = 0
+        for k in range(6):
+            v |= b.splitmix_at(seed, 6 * i + k) << (64 * k)
+        return v % self.r
+
+    def witness_like_scalar(self, seed, i):
+        sel = b.splitmix_at(seed ^ 0x5EED5EED5EED5EED, i) % 100
+        if sel < 40: return 0
+        if sel < 65: return 1
+        if sel < 90: return b.splitmix_at(seed, 6 * i)
+        return self.fr_at(seed, i)
+
+    def progression(self, base, seed, n):
+        """P_i = [s0]B + i*[s1]B, (s0, s1) = the first two raw 256-bit blocks of stream `seed`
+        (dvn_bw6761_points_synthetic)."""
+        s0 = sum(b.splitmix_at(seed, k) << (64 * k) for k in range(4))
+        s1 = sum(b.splitmix_at(seed, 4 + k) << (64 * k) for k in range(4))
+        p0, d = self.mul(base, s0), self.mul(base, s1)
+        out, cur = [], p0
+        for _ in range(n):
+            out.append(cur); cur = self.add(cur, d)
+        return out
+
+
+BW6_761 = Bw6761()
