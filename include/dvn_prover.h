@@ -214,8 +214,8 @@ int32_t dvn_bls12377_ntt(dvn_ctx* ctx, const dvn_domain* dom, uint64_t* data, in
                          uint32_t flags);
 
 /* ---- BW6-761 -------------------------------------------------------------------------------------- */
-/* The aggregator's curve (/root/reference/spec/params/params.go:24; one 2^24..2^25-constraint proof per batch; in the
- * reference this curve always takes the CPU fallback, prover/prover_gpu.go:36-43,59).  G1 (y^2 = x^3 - 1) and G2
+/* The aggregator's curve (/root/reference/spec/params/params.go:24; one proof per batch; reference GPU dispatch
+ * prover/prover_gpu.go:52-57).  G1 (y^2 = x^3 - 1) and G2
  * (y^2 = x^3 + 4) both live over the 761-bit base field, so one entry point serves both; `group` (1 or 2) is recorded in
  * the handle.  gnark images: fp.Element 12 x uint64 (R = 2^768), G1Affine/G2Affine 24 x uint64, G1Jac/G2Jac 36 x uint64;
  * scalars are fr.Element = 6 x uint64 (R = 2^384; the field is BLS12-377's base field).  MSM only: the BW6-761 scalar
