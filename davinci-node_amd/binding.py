@@ -99,6 +99,15 @@ def load_library():
         "dvn_bls12377_msm_g2": (i32, [vp, vp, sz, sz, vp, u32, vp]),
         "dvn_bls12377_ntt_domain": (i32, [vp, u32, C.POINTER(vp)]),
         "dvn_bls12377_ntt": (i32, [vp, vp, vp, C.c_int, C.c_int, C.c_int, u32]),
+        "dvn_bls12381_points_upload_g1": (i32, [vp, vp, sz, C.POINTER(vp)]),
+        "dvn_bls12381_points_upload_g2": (i32, [vp, vp, sz, C.POINTER(vp)]),
+        "dvn_bls12381_points_synthetic_g1": (i32, [vp, u64, sz, C.POINTER(vp)]),
+        "dvn_bls12381_points_download": (i32, [vp, vp, sz, sz, vp]),
+        "dvn_bls12381_scalars_synthetic": (i32, [vp, u64, C.c_int, sz, vp]),
+        "dvn_bls12381_msm_g1": (i32, [vp, vp, sz, sz, vp, u32, vp]),
+        "dvn_bls12381_msm_g2": (i32, [vp, vp, sz, sz, vp, u32, vp]),
+        "dvn_bls12381_ntt_domain": (i32, [vp, u32, C.POINTER(vp)]),
+        "dvn_bls12381_ntt": (i32, [vp, vp, vp, C.c_int, C.c_int, C.c_int, u32]),
         "dvn_bw6761_points_upload": (i32, [vp, C.c_int, vp, sz, C.POINTER(vp)]),
         "dvn_bw6761_points_synthetic": (i32, [vp, C.c_int, vp, u64, sz, C.POINTER(vp)]),
         "dvn_bw6761_points_download": (i32, [vp, vp, sz, sz, vp]),
@@ -131,6 +140,8 @@ EXPORTED_SYMBOLS = [
     "dvn_groth16_proof_abi_encode", "dvn_pedersen_commit",
     "dvn_bls12377_points_upload_g1", "dvn_bls12377_points_upload_g2", "dvn_bls12377_points_synthetic_g1", "dvn_bls12377_points_download",
     "dvn_bls12377_scalars_synthetic", "dvn_bls12377_msm_g1", "dvn_bls12377_msm_g2", "dvn_bls12377_ntt_domain", "dvn_bls12377_ntt",
+    "dvn_bls12381_points_upload_g1", "dvn_bls12381_points_upload_g2", "dvn_bls12381_points_synthetic_g1", "dvn_bls12381_points_download",
+    "dvn_bls12381_scalars_synthetic", "dvn_bls12381_msm_g1", "dvn_bls12381_msm_g2", "dvn_bls12381_ntt_domain", "dvn_bls12381_ntt",
     "dvn_bw6761_points_upload", "dvn_bw6761_points_synthetic", "dvn_bw6761_points_download", "dvn_bw6761_scalars_synthetic", "dvn_bw6761_msm",
     "dvn_prover_use_gpu", "dvn_prover_set_use_gpu", "dvn_prover_reload_env", "dvn_prover_set_prover", "dvn_prover_set_cpu_backend",
     "dvn_prover_last_backend", "dvn_prover_prove", "dvn_prover_setup",
@@ -419,58 +430,67 @@ class Groth16Key:
 
 class Bls12377:
     """BLS12-377 entry points over an existing Context.  Points: (n,12) G1 / (n,24) G2 uint64."""
+    PREFIX = "dvn_bls12377_"
+
+    def _f(self, name):
+        return getattr(self.L, self.PREFIX + name)
 
     def __init__(self, ctx: Context):
         self.ctx, self.L = ctx, ctx.L
 
     def upload_g1(self, xy: np.ndarray) -> Points:
         xy = np.ascontiguousarray(xy, dtype=np.uint64).reshape(-1, 12)
-        p = C.c_void_p(); self.ctx._chk(self.L.dvn_bls12377_points_upload_g1(self.ctx.h, _host(xy), xy.shape[0], C.byref(p)))
+        p = C.c_void_p(); self.ctx._chk(self._f("points_upload_g1")(self.ctx.h, _host(xy), xy.shape[0], C.byref(p)))
         return Points(self.ctx, p, 1)
 
     def upload_g2(self, xy: np.ndarray) -> Points:
         xy = np.ascontiguousarray(xy, dtype=np.uint64).reshape(-1, 24)
-        p = C.c_void_p(); self.ctx._chk(self.L.dvn_bls12377_points_upload_g2(self.ctx.h, _host(xy), xy.shape[0], C.byref(p)))
+        p = C.c_void_p(); self.ctx._chk(self._f("points_upload_g2")(self.ctx.h, _host(xy), xy.shape[0], C.byref(p)))
         return Points(self.ctx, p, 2)
 
     def synthetic_g1(self, seed: int, n: int) -> Points:
-        p = C.c_void_p(); self.ctx._chk(self.L.dvn_bls12377_points_synthetic_g1(self.ctx.h, seed, n, C.byref(p)))
+        p = C.c_void_p(); self.ctx._chk(self._f("points_synthetic_g1")(self.ctx.h, seed, n, C.byref(p)))
         return Points(self.ctx, p, 1)
 
     def download(self, pts: Points, off: int = 0, n: int | None = None) -> np.ndarray:
         n = len(pts) - off if n is None else n
         out = np.zeros((n, 12 if pts.curve == 1 else 24), dtype=np.uint64)
-        self.ctx._chk(self.L.dvn_bls12377_points_download(self.ctx.h, pts.handle, off, n, _host(out)))
+        self.ctx._chk(self._f("points_download")(self.ctx.h, pts.handle, off, n, _host(out)))
         return out
 
     def synthetic_scalars(self, seed: int, kind: int, n: int) -> int:
         d = self.ctx.malloc(n * 32)
-        self.ctx._chk(self.L.dvn_bls12377_scalars_synthetic(self.ctx.h, seed, kind, n, C.c_void_p(d)))
+        self.ctx._chk(self._f("scalars_synthetic")(self.ctx.h, seed, kind, n, C.c_void_p(d)))
         return d
 
     def msm_g1(self, pts: Points, scalars, off: int = 0, n: int | None = None) -> np.ndarray:
         sp, ns, fl = self.ctx._scalars(scalars, n)
         out = np.zeros(18, dtype=np.uint64)
-        self.ctx._chk(self.L.dvn_bls12377_msm_g1(self.ctx.h, pts.handle, off, ns, sp, fl, _host(out)))
+        self.ctx._chk(self._f("msm_g1")(self.ctx.h, pts.handle, off, ns, sp, fl, _host(out)))
         return out
 
     def msm_g2(self, pts: Points, scalars, off: int = 0, n: int | None = None) -> np.ndarray:
         sp, ns, fl = self.ctx._scalars(scalars, n)
         out = np.zeros(36, dtype=np.uint64)
-        self.ctx._chk(self.L.dvn_bls12377_msm_g2(self.ctx.h, pts.handle, off, ns, sp, fl, _host(out)))
+        self.ctx._chk(self._f("msm_g2")(self.ctx.h, pts.handle, off, ns, sp, fl, _host(out)))
         return out
 
     def domain(self, log_n: int) -> Domain:
-        p = C.c_void_p(); self.ctx._chk(self.L.dvn_bls12377_ntt_domain(self.ctx.h, log_n, C.byref(p)))
+        p = C.c_void_p(); self.ctx._chk(self._f("ntt_domain")(self.ctx.h, log_n, C.byref(p)))
         return Domain(self.ctx, p, log_n)
 
     def ntt(self, dom: Domain, data, inverse: bool, decimation: int, coset: bool = False):
         if isinstance(data, (int, np.integer)):
-            self.ctx._chk(self.L.dvn_bls12377_ntt(self.ctx.h, dom.handle, C.c_void_p(int(data)), int(inverse), decimation, int(coset), NTT_DATA_ON_DEVICE))
+            self.ctx._chk(self._f("ntt")(self.ctx.h, dom.handle, C.c_void_p(int(data)), int(inverse), decimation, int(coset), NTT_DATA_ON_DEVICE))
             return data
         assert data.dtype == np.uint64 and data.flags["C_CONTIGUOUS"] and data.shape == (dom.n, 4)
-        self.ctx._chk(self.L.dvn_bls12377_ntt(self.ctx.h, dom.handle, _host(data), int(inverse), decimation, int(coset), 0))
+        self.ctx._chk(self._f("ntt")(self.ctx.h, dom.handle, _host(data), int(inverse), decimation, int(coset), 0))
         return data
+
+
+class Bls12381(Bls12377):
+    """BLS12-381 entry points (the blob-KZG curve): same element sizes as BLS12-377."""
+    PREFIX = "dvn_bls12381_"
 
 
 class Bw6761:

@@ -165,6 +165,8 @@ typedef Curve<Fp2> G2;
 // BLS12-377 (voteverifier curve): same a = 0 group law over 14-limb base-field elements
 typedef Curve<Fp377> G1_377;
 typedef Curve<Fp2_377> G2_377;
+typedef Curve<Fp381> G1_381;
+typedef Curve<Fp2_381> G2_381;
 // BW6-761 (aggregator curve): G1 and G2 are both curves over the 761-bit base field (27 limbs)
 typedef Curve<Fp761> G_761;
 

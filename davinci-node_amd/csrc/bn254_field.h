@@ -346,6 +346,7 @@ template <class C> struct Fe2 { Fe<C> a0, a1; };
 template <class C> struct Beta;
 template <> struct Beta<FpCfg> { static constexpr int value = 1; };
 template <> struct Beta<Fp377Cfg> { static constexpr int value = 5; };
+template <> struct Beta<Fp381Cfg> { static constexpr int value = 1; };
 
 typedef Fe<FpCfg> Fp;
 typedef Fe<FrCfg> Fr;
@@ -354,6 +355,9 @@ typedef Fe<Fp377Cfg> Fp377;
 typedef Fe<Fr377Cfg> Fr377;
 typedef Fe2<Fp377Cfg> Fp2_377;
 typedef Fe<Fp761Cfg> Fp761;
+typedef Fe<Fp381Cfg> Fp381;
+typedef Fe<Fr381Cfg> Fr381;
+typedef Fe2<Fp381Cfg> Fp2_381;
 
 // Uniform "field ops" interface used by the curve templates
 template <class F> struct Ops;
@@ -382,7 +386,7 @@ template <class C> struct Ops<Fe<C>> {
     static constexpr bool OUTLINE = false;
     // Curve::acc_add_mixed uses the lazily reduced formulas where the 64-bit column accumulators have the headroom:
     // 3 x NL products of < 2^58 (+ limbs up to 2^30) must stay below 2^64 -> NL <= 16
-    static constexpr bool LAZY = C::NL <= 16;
+    static constexpr bool LAZY = C::NL <= 16 && C::SLACK >= 169;
     static DVN_HD F load_internal(const u32* w) { u32 t[C::EW];
 #pragma unroll
         for (int i = 0; i < C::EW; ++i) t[i] = w[i];

@@ -136,6 +136,28 @@ void hc377_g1_acc_chain(const uint32_t* pts, const uint32_t* idx, size_t n, uint
 }
 }
 
+// ---- BLS12-381 (same shapes as BLS12-377; u^2 = -1; 255-bit scalar field on 9 limbs with R'/r = 70) ----------------------
+extern "C" {
+void hc381_fp_op(const uint32_t* a, const uint32_t* b, uint32_t* r, int op) { bin12<Fp381Cfg>(a, b, r, op); }
+void hc381_fr_op(const uint32_t* a, const uint32_t* b, uint32_t* r, int op) { bin12<Fr381Cfg>(a, b, r, op); }
+void hc381_fr_ext_to_canonical(const uint32_t* a, uint32_t* r) {
+    u32 wa[8], wr[8]; memcpy(wa, a, 32);
+    fe_pack<Fr381Cfg>(fe_ext_mont_to_canonical<Fr381Cfg>(wa), wr); memcpy(r, wr, 32);
+}
+void hc381_g1_msm_naive(const uint32_t* pts, const uint32_t* k, size_t n, uint32_t* out) { msm_naive<G1_381>(pts, k, n, out); }
+void hc381_g2_msm_naive(const uint32_t* pts, const uint32_t* k, size_t n, uint32_t* out) { msm_naive<G2_381>(pts, k, n, out); }
+// lazily reduced accumulator chain over G1-381 (the k_accumulate loop body)
+void hc381_g1_acc_chain(const uint32_t* pts, const uint32_t* idx, size_t n, uint32_t* out) {
+    G1_381::X acc = G1_381::infinity();
+    for (size_t i = 0; i < n; ++i) {
+        G1_381::A p = G1_381::affine_from_ext(pts + (size_t)G1_381::AW * (idx[i] & 0x7fffffffu));
+        if (idx[i] & 0x80000000u) p = G1_381::neg(p);
+        acc = G1_381::acc_add_mixed(acc, p);
+    }
+    G1_381::affine_to_ext(G1_381::to_affine(G1_381::acc_normalize(acc)), out);
+}
+}
+
 // ---- BW6-761 (27 x 29-bit limbs, external 12 x u64; scalars 377 bits = 12 words) ----------------------------------------
 template <class Cv, int KW> static void msm_naive_wide(const uint32_t* pts, const uint32_t* k, size_t n, uint32_t* out) {
     typename Cv::X acc = Cv::infinity();

@@ -14,6 +14,10 @@ template <> struct ScalarOf<G2_377> { typedef Fr377Cfg S; };
 template <class Cv> struct SuiteOf { static constexpr int value = 0; };          // 0 = BN254, 1 = BLS12-377
 template <> struct SuiteOf<G1_377> { static constexpr int value = 1; };
 template <> struct SuiteOf<G2_377> { static constexpr int value = 1; };
+template <> struct ScalarOf<G1_381> { typedef Fr381Cfg S; };
+template <> struct ScalarOf<G2_381> { typedef Fr381Cfg S; };
+template <> struct SuiteOf<G1_381> { static constexpr int value = 3; };               // 3 = BLS12-381
+template <> struct SuiteOf<G2_381> { static constexpr int value = 3; };
 template <> struct ScalarOf<G_761> { typedef Fp377Cfg S; };                          // BW6-761's scalar field is BLS12-377's base field
 template <> struct SuiteOf<G_761> { static constexpr int value = 2; };               // 2 = BW6-761
 template <class F> struct IsQuadratic { static constexpr bool value = false; };

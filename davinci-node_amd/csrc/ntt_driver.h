@@ -14,6 +14,10 @@ template <> struct DomainConsts<Fr377Cfg> {   // w_{2^47} = 22^((r-1)/2^47) = gn
     static constexpr u32 ADICITY = 47; static constexpr u64 COSET_GEN = 22; static constexpr int SUITE = 1;
     static const u64* root() { static const u64 r[4] = {0x476ef4a4ec2a895eULL, 0x9b506ee363e3f04aULL, 0x60c69477d1a8a12fULL, 0x11d4b7f60cb92cc1ULL}; return r; }
 };
+template <> struct DomainConsts<Fr381Cfg> {   // w_{2^32} = 7^((r-1)/2^32) = 10238227357739495823651030575849232062558860180284477541189508159991286009131
+    static constexpr u32 ADICITY = 32; static constexpr u64 COSET_GEN = 7; static constexpr int SUITE = 3;
+    static const u64* root() { static const u64 r[4] = {0x3829971f439f0d2bULL, 0xb63683508c2280b9ULL, 0xd09b681922c813b4ULL, 0x16a2a19edfe81f20ULL}; return r; }
+};
 
 // ------------------------------------------------------------------------------------------------------
 // NTT

@@ -69,6 +69,20 @@ template <class S> __device__ __forceinline__ Fe<S> ntt_scale_factor(const NttSc
 // values < 4p (the in-pass invariant) -> canonical -> 8 words
 template <class S> __device__ __forceinline__ void st_fr4(const Fe<S>& v, u32* __restrict__ p) { st_fr<S>(fe_csub<S, 2>(v), p); }
 
+// In-pass reduction of a value < 8p to what an 8-word LDS slot can hold: below 4p when 4p < 2^256 (BN254 and BLS12-377,
+// 254/253-bit moduli), below 2p for a 255-bit modulus (BLS12-381: 4p > 2^256), at the price of a second conditional
+// subtraction.
+template <class S> struct NttSlot { static constexpr bool WIDE = S::BITS + 2 <= 32 * S::EW; };
+template <class S> __device__ __forceinline__ Fe<S> ntt_red(const Fe<S>& x) {
+    if constexpr (NttSlot<S>::WIDE) return fe_csub<S, 4>(x);
+    else return fe_csub<S, 2>(fe_csub<S, 4>(x));
+}
+// a sum of two fresh products (< 2.5p): fits a wide slot as it is
+template <class S> __device__ __forceinline__ Fe<S> ntt_red_small(const Fe<S>& x) {
+    if constexpr (NttSlot<S>::WIDE) return x;
+    else return fe_csub<S, 2>(x);
+}
+
 // stages [sa, sb) of a 2^log_n transform; dit = 0: ascending s (DIF), dit = 1: descending s (DIT).
 // Two stages per LDS round trip (radix-4 units held in registers); values in LDS are kept below 4p ("loose", limbs
 // normalised), so differences feed the twiddle multiplication after ONE carry pass and sums need one conditional
@@ -118,11 +132,11 @@ template <class S> __global__ __launch_bounds__(512) void k_ntt_pass(u32* __rest
                 const Fr wa0 = ld_fr<S>(tab1 + (size_t)((low << Lb) | inner) * 8);
                 const Fr wa1 = ld_fr<S>(tab1 + (size_t)((((1u << dlo) | low) << Lb) | inner) * 8);
                 const Fr wb = ld_fr<S>(tab2 + (size_t)((low << Lb) | inner) * 8);
-                const Fr A0 = fe_csub<C, 4>(fe_add_lazy<C>(x00, x10)), A1 = fe_csub<C, 4>(fe_add_lazy<C>(x01, x11));
+                const Fr A0 = ntt_red<S>(fe_add_lazy<C>(x00, x10)), A1 = ntt_red<S>(fe_add_lazy<C>(x01, x11));
                 const Fr B0 = fe_mul<C>(fe_sub_lazy<C, 4>(x00, x10), wa0), B1 = fe_mul<C>(fe_sub_lazy<C, 4>(x01, x11), wa1);
-                st_fr_weak<S>(fe_csub<C, 4>(fe_add_lazy<C>(A0, A1)), p00);
+                st_fr_weak<S>(ntt_red<S>(fe_add_lazy<C>(A0, A1)), p00);
                 st_fr_weak<S>(fe_mul<C>(fe_sub_lazy<C, 4>(A0, A1), wb), p01);
-                st_fr_weak<S>(fe_add_lazy<C>(B0, B1), p10);
+                st_fr_weak<S>(ntt_red_small<S>(fe_add_lazy<C>(B0, B1)), p10);
                 st_fr_weak<S>(fe_mul<C>(fe_sub_lazy<C, 2>(B0, B1), wb), p11);
             } else {
                 // stage s1 pairs over the LOW bit, one twiddle; stage s1-1 pairs over the HIGH bit, twiddle depends on the low bit
@@ -133,10 +147,10 @@ template <class S> __global__ __launch_bounds__(512) void k_ntt_pass(u32* __rest
                 const Fr a00 = fe_add_lazy<C>(x00, t0), a01 = fe_sub_lazy<C, 2>(x00, t0);     // < 5.1p, < 6p
                 const Fr a10 = fe_add_lazy<C>(x10, t1), a11 = fe_sub_lazy<C, 2>(x10, t1);
                 const Fr u0 = fe_mul<C>(a10, w20), u1 = fe_mul<C>(a11, w21);
-                st_fr_weak<S>(fe_csub<C, 4>(fe_add_lazy<C>(a00, u0)), p00);
-                st_fr_weak<S>(fe_csub<C, 4>(fe_add_lazy<C>(a01, u1)), p01);
-                st_fr_weak<S>(fe_csub<C, 4>(fe_sub_lazy<C, 2>(a00, u0)), p10);
-                st_fr_weak<S>(fe_csub<C, 4>(fe_sub_lazy<C, 2>(a01, u1)), p11);
+                st_fr_weak<S>(ntt_red<S>(fe_add_lazy<C>(a00, u0)), p00);
+                st_fr_weak<S>(ntt_red<S>(fe_add_lazy<C>(a01, u1)), p01);
+                st_fr_weak<S>(ntt_red<S>(fe_sub_lazy<C, 2>(a00, u0)), p10);
+                st_fr_weak<S>(ntt_red<S>(fe_sub_lazy<C, 2>(a01, u1)), p11);
             }
         }
         __syncthreads();
@@ -157,12 +171,12 @@ template <class S> __global__ __launch_bounds__(512) void k_ntt_pass(u32* __rest
             u32* pb = lds + (size_t)((D1 << log_i) | q) * 8;
             const Fr a = ld_fr<S>(pa), b = ld_fr<S>(pb);
             if (!dit) {
-                st_fr_weak<S>(fe_csub<C, 4>(fe_add_lazy<C>(a, b)), pa);
+                st_fr_weak<S>(ntt_red<S>(fe_add_lazy<C>(a, b)), pa);
                 st_fr_weak<S>(fe_mul<C>(fe_sub_lazy<C, 4>(a, b), w), pb);
             } else {
                 const Fr bt = fe_mul<C>(b, w);
-                st_fr_weak<S>(fe_csub<C, 4>(fe_add_lazy<C>(a, bt)), pa);
-                st_fr_weak<S>(fe_csub<C, 4>(fe_sub_lazy<C, 2>(a, bt)), pb);
+                st_fr_weak<S>(ntt_red<S>(fe_add_lazy<C>(a, bt)), pa);
+                st_fr_weak<S>(ntt_red<S>(fe_sub_lazy<C, 2>(a, bt)), pb);
             }
         }
         __syncthreads();

@@ -213,6 +213,24 @@ int32_t dvn_bls12377_ntt_domain(dvn_ctx* ctx, uint32_t log_n, dvn_domain** out);
 int32_t dvn_bls12377_ntt(dvn_ctx* ctx, const dvn_domain* dom, uint64_t* data, int inverse, int decimation, int on_coset,
                          uint32_t flags);
 
+/* ---- BLS12-381 ------------------------------------------------------------------------------------ */
+/* The fourth curve of the reference's GPU dispatch (/root/reference/prover/prover_gpu.go:45-50) and the curve of the
+ * EIP-4844 blob commitment computed before every state-transition proof: a 4096-point G1 MSM over the KZG setup in
+ * Lagrange form (/root/reference/crypto/blobs/blob.go:40-90, types/blobs.go:90-160).  Element images have the sizes of
+ * BLS12-377 (fp 6 x uint64, fr 4 x uint64; E2 = A0 + A1 u with u^2 = -1); scalar-field NTT with coset shift 7. */
+int32_t dvn_bls12381_points_upload_g1(dvn_ctx* ctx, const uint64_t* xy_mont /* n x 12 */, size_t n, dvn_points** out);
+int32_t dvn_bls12381_points_upload_g2(dvn_ctx* ctx, const uint64_t* xy_mont /* n x 24 */, size_t n, dvn_points** out);
+int32_t dvn_bls12381_points_synthetic_g1(dvn_ctx* ctx, uint64_t seed, size_t n, dvn_points** out);
+int32_t dvn_bls12381_points_download(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, uint64_t* xy_mont);
+int32_t dvn_bls12381_scalars_synthetic(dvn_ctx* ctx, uint64_t seed, int kind, size_t n, void* d_out);
+int32_t dvn_bls12381_msm_g1(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars_mont,
+                            uint32_t flags, uint64_t out_jac[18]);
+int32_t dvn_bls12381_msm_g2(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars_mont,
+                            uint32_t flags, uint64_t out_jac[36]);
+int32_t dvn_bls12381_ntt_domain(dvn_ctx* ctx, uint32_t log_n, dvn_domain** out);      /* log_n <= 27 (two-adicity 32) */
+int32_t dvn_bls12381_ntt(dvn_ctx* ctx, const dvn_domain* dom, uint64_t* data, int inverse, int decimation, int on_coset,
+                         uint32_t flags);
+
 /* ---- BW6-761 -------------------------------------------------------------------------------------- */
 /* The aggregator's curve (/root/reference/spec/params/params.go:24; one proof per batch; reference GPU dispatch
  * prover/prover_gpu.go:52-57).  G1 (y^2 = x^3 - 1) and G2

@@ -255,6 +255,14 @@ BLS12_377 = Suite(
     g1_gen=(0x008848DEFE740A67C8FC6225BF87FF5485951E2CAA9D41BB188282C8BD37CB5CD5481512FFCD394EEAB9B16EB21BE9EF,
             0x01914A69C5102EFF1F674F5D30AFEEC4BD7FB348CA3E52D96D182AD44FB82305C2FE3D3634A9591AFD82DE55559C8EA6),
     fr_gen=22, two_adicity=47)
+_P381 = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+_R381 = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+# BLS12-381 (blob KZG; prover_gpu.go:45-50): y^2 = x^3 + 4, twist y^2 = x^3 + 4(1 + u), u^2 = -1, Fr generator 7
+BLS12_381 = Suite(
+    "bls12-381", _P381, _R381, b_g1=4, beta=1, b_g2=(4, 4),
+    g1_gen=(0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB,
+            0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1),
+    fr_gen=7, two_adicity=32)
 BN254 = Suite("bn254", b.P, b.R, b_g1=3, beta=1, b_g2=b.B_G2, g1_gen=b.G1_GEN, fr_gen=5, two_adicity=28)
 
 

@@ -1,6 +1,7 @@
-"""BLS12-377 (the voteverifier curve): the same HIP kernels instantiated on 14-limb base-field
-elements, checked against the curve-generic Python oracle (oracle/curves_py.py).  Parity unpinned by the reference
-(no vectors); the oracle's constants are cross-checked in test_bls12377_constants."""
+"""BLS12-377 (the voteverifier curve) and BLS12-381 (row f3; blob KZG, the fourth curve of
+prover_gpu.go's dispatch): the same HIP kernels instantiated on 14-limb base-field elements, checked against the
+curve-generic Python oracle (oracle/curves_py.py).  Parity unpinned by the reference (no vectors); the oracle's
+constants are cross-checked in test_bls12377_constants / test_bls12381_constants."""
 import ctypes as C
 import os
 import subprocess
@@ -12,10 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "davinci-node_amd", "csrc")
 
 
-@pytest.fixture(scope="module")
-def S():
+@pytest.fixture(scope="module", params=["bls12-377", "bls12-381"])
+def S(request):
     from oracle import curves_py
-    return curves_py.BLS12_377
+    return curves_py.BLS12_377 if request.param == "bls12-377" else curves_py.BLS12_381
 
 
 def jac_to_affine(S, j, g2=False):
@@ -27,7 +28,28 @@ def jac_to_affine(S, j, g2=False):
     return j[:2 * n].copy()
 
 
-def test_bls12377_constants(S, opy):
+def test_bls12381_constants(opy):
+    from oracle import curves_py
+    S = curves_py.BLS12_381
+    assert S.p.bit_length() == 381 and S.r.bit_length() == 255
+    assert S.g1_on_curve(S.g1_gen) and S.g1_mul(S.g1_gen, S.r) is None
+    assert (S.r - 1) % (1 << 32) == 0 and (S.r - 1) % (1 << 33) != 0
+    assert S.root == 10238227357739495823651030575849232062558860180284477541189508159991286009131   # gnark-crypto fr/fft
+    assert pow(S.root, 1 << 31, S.r) == S.r - 1
+    assert pow(S.p - 1, (S.p - 1) // 2, S.p) == S.p - 1          # -1 is a non-residue: Fp2 = Fp[u]/(u^2+1)
+    # 7 generates Fr*: r - 1 = 2^32 * 3 * 11 * 19 * (214-bit cofactor whose primes are large); the small ones:
+    assert all(pow(7, (S.r - 1) // q, S.r) != 1 for q in (2, 3, 11, 19))
+    q = S.g2_some_point(3)
+    assert S.g2_on_curve(q) and S.g2_on_curve(S.g2_add(q, q)) and S.g2_on_curve(S.g2_mul(q, 12345))
+    d = S.domain(8); a = [S.fr_at(7, i) for i in range(8)]
+    ref = [sum(a[j] * pow(d.gen, i * j, S.r) for j in range(8)) % S.r for i in range(8)]
+    x = list(a); d.fft(x, opy.DIF)
+    assert [x[opy.bitrev(i, 3)] for i in range(8)] == ref
+
+
+def test_bls12377_constants(opy):
+    from oracle import curves_py
+    S = curves_py.BLS12_377
     assert S.p.bit_length() == 377 and S.r.bit_length() == 253
     assert S.g1_on_curve(S.g1_gen) and S.g1_mul(S.g1_gen, S.r) is None
     assert (S.r - 1) % (1 << 47) == 0 and (S.r - 1) % (1 << 48) != 0
@@ -56,7 +78,8 @@ def test_bls12377_host_arithmetic(S, opy):
         for i in range(6):
             v |= rng.next() << (64 * i)
         return v % mod
-    for mod, fn, nl, tm in ((S.p, lib.hc377_fp_op, 6, S.fp_to_mont), (S.r, lib.hc377_fr_op, 4, S.fr_to_mont)):
+    hc = lambda name: getattr(lib, ("hc377_" if S.name == "bls12-377" else "hc381_") + name)
+    for mod, fn, nl, tm in ((S.p, hc("fp_op"), 6, S.fp_to_mont), (S.r, hc("fr_op"), 4, S.fr_to_mont)):
         L = lambda x: np.array(S.limbs(tm(x), nl), dtype=np.uint64)
         for it in range(600):
             a, b = rnd(mod), rnd(mod)
@@ -71,14 +94,14 @@ def test_bls12377_host_arithmetic(S, opy):
                 assert opy.from_limbs(r) == tm(pow(a, -1, mod) if a else 0)
     pts = S.synthetic_g1_points(9, 8); ks = [S.fr_at(3, i) for i in range(8)]; ks[3] = 0; ks[4] = 1; ks[5] = S.r - 1
     pa = np.array([S.g1_to_limbs(q) for q in pts], dtype=np.uint64); ka = np.array([S.limbs(k, 4) for k in ks], dtype=np.uint64)
-    r = np.zeros(12, dtype=np.uint64); lib.hc377_g1_msm_naive(p(pa), p(ka), C.c_size_t(8), p(r))
+    r = np.zeros(12, dtype=np.uint64); hc("g1_msm_naive")(p(pa), p(ka), C.c_size_t(8), p(r))
     assert list(r) == S.g1_to_limbs(S.g1_msm(pts, ks))
     q = S.synthetic_g2_points(4, 4); qa = np.array([S.g2_to_limbs(x) for x in q], dtype=np.uint64)
-    r2 = np.zeros(24, dtype=np.uint64); lib.hc377_g2_msm_naive(p(qa), p(ka), C.c_size_t(4), p(r2))
+    r2 = np.zeros(24, dtype=np.uint64); hc("g2_msm_naive")(p(qa), p(ka), C.c_size_t(4), p(r2))
     assert list(r2) == S.g2_to_limbs(S.g2_msm(q, ks[:4]))
     for idx in ([0, 1, 2, 3], [5, 5], [5, 5 | (1 << 31)], [5, 5 | (1 << 31), 7], [3] * 20):
         ia = np.array(idx, dtype=np.uint32); r = np.zeros(12, dtype=np.uint64)
-        lib.hc377_g1_acc_chain(p(pa), p(ia), C.c_size_t(len(idx)), p(r))
+        hc("g1_acc_chain")(p(pa), p(ia), C.c_size_t(len(idx)), p(r))
         acc = None
         for e in idx:
             pt = pts[e & 0x7fffffff]; pt = S.g1_neg(pt) if e >> 31 else pt; acc = S.g1_add(acc, pt)
@@ -86,8 +109,8 @@ def test_bls12377_host_arithmetic(S, opy):
 
 
 @pytest.fixture(scope="module")
-def bls(ctx, pkg):
-    return pkg.Bls12377(ctx)
+def bls(ctx, pkg, S):
+    return pkg.Bls12377(ctx) if S.name == "bls12-377" else pkg.Bls12381(ctx)
 
 
 @pytest.mark.gpu
@@ -120,7 +143,7 @@ def test_bls12377_msm_g1_vs_oracle(bls, ctx, S):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("log_n", [14, 18])
+@pytest.mark.parametrize("log_n", [12, 14, 18])
 def test_bls12377_msm_g1_closed_form(bls, ctx, S, log_n):
     """Device-generated P_i = P0 + i D: sum s_i P_i = (sum s_i) P0 + (sum i s_i) D with Python big ints."""
     n = 1 << log_n
@@ -196,7 +219,7 @@ def test_bls12377_ntt_large_properties(bls, ctx, S, pkg):
     one = np.array(S.fr_to_limbs(1), dtype=np.uint64)
     delta = np.zeros_like(x); delta[1] = one
     ctx.h2d(dx, delta); bls.ntt(dom, dx, False, pkg.DIF, False); ctx.d2h(y, dx)
-    w = pow(S.root, 1 << (47 - log_n), S.r)
+    w = pow(S.root, 1 << (S.two_adicity - log_n), S.r)
     assert S.fr_from_limbs(y[0]) == 1 and S.fr_from_limbs(y[1]) == S.r - 1          # w^0, w^(n/2)
     assert S.fr_from_limbs(y[2]) == pow(w, n // 4, S.r) and S.fr_from_limbs(y[3]) == pow(w, 3 * n // 4, S.r)
     ctx.free(dx); dom.free()

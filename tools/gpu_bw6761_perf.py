@@ -14,7 +14,7 @@ while True:
     x += 1
 m = lambda v: [((v << 768) % p >> (64 * i)) & (2 ** 64 - 1) for i in range(12)]
 base = np.array(m(x) + m(y), dtype=np.uint64)
-for log_n in (16, 18, 20):
+for log_n in (16, 20, 22, 24):
     n = 1 << log_n
     pts = bw.synthetic(1, base, 0xDA71C1, n); d = bw.synthetic_scalars(1, 0, n)
     for rep in range(3):
