@@ -412,6 +412,7 @@ template <class C> struct OpsCall : Ops<Fe<C>> {
 };
 template <class C> struct Ops<Fe2<C>> {
     typedef Fe2<C> F;
+    static constexpr bool CALL_MUL = true;     // the base-field products are real calls (OpsCall)
     typedef OpsCall<C> B;
     static constexpr int BETA = Beta<C>::value;
     // BETA * x for the small positive BETA (1 or 5): additions only

@@ -163,16 +163,159 @@ template <class Cv> static u32 pick_segment(size_t total) {
 // window sums for windows [win_lo, win_hi) -> host, internal packed xyzz images (XW words each)
 // ENQUEUE only: the kernels and the D2H copy of the window sums (into L.h_sums) are queued on the lane's stream;
 // lane_wait() completes them.
+// The sliced reduction of giant buckets (k_giant_*) runs only on curves whose field arithmetic is fully inlined.  On the
+// call-based instantiations (Fp2 curves, BW6-761: scratch-backed stack frames) the same kernels returned wrong sums and
+// memory faults on gfx950 while the G1 instantiation of the identical source checked out slice by slice; until that is
+// understood those curves keep the one-block-per-bucket path of k_fix_heavy.
+template <class Cv> struct GiantOk { static constexpr bool value = !Cv::O::CALL_MUL; };
+static inline u32 giant_threshold() {       // DVN_MSM_GIANT=<segments> overrides (debug / A-B); never below FIX_GIANT: giant_cap assumes it
+    static const u32 v = []() { const char* e = getenv("DVN_MSM_GIANT"); const long x = e ? atol(e) : 0; return x > (long)FIX_GIANT ? (u32)x : FIX_GIANT; }();
+    return v;
+}
+// LDS limits of the staged sort kernels (dynamic LDS above the 64 KiB default needs the attribute once per kernel)
+template <class D> static int32_t sort_attrs() {
+    static bool done = false;
+    if (!done) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_s1_scatter<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_s2_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        done = true;
+    }
+    return DVN_OK;
+}
+static inline size_t s1_lds(u32 lb) { return ((size_t)3 * lb + 80 + 2 * ST) * 4; }
+static inline size_t s2_lds() { return ((size_t)4 * 1024 + 80 + ST) * 4 + (size_t)ST * 2; }
+
+// Plain point sets, two-pass staged sort: one globally sorted entry list over the virtual buckets (window, bucket);
+// the accumulate / fix kernels see ONE window of W * nb buckets, the reduction runs per real window afterwards.
+template <class Cv>
+static int32_t msm_windows_staged(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
+                                  u32 c, u32 win_lo, u32 win_hi) {
+    const u32 W = win_hi - win_lo;
+    const u32 nb = 1u << (c - 1);
+    const u32 lob = c - 1 < 7 ? c - 1 : 7, lb = nb >> lob;             // <= 256 bins per window, 2^lob sub-buckets per bin
+    const size_t total = (size_t)W * n;
+    if (total >= ((size_t)1 << 31)) return fail(DVN_ERR_INVALID_ARG, "MSM too large for 31-bit entry positions");
+    const u32 vb = W * nb;                                             // virtual buckets
+    const u32 seg = pick_segment<Cv>(total);
+    const u32 nseg = (u32)((total + seg - 1) / seg);
+    const u32 LB8 = 8;
+    const u32 bpw = (nb + 256 * LB8 - 1) / (256 * LB8);
+    const u32 heavy_cap = (u32)(nseg / (FIX_LIGHT - 1) + 1);
+    const u32 giant_cap = heavy_cap / (FIX_GIANT / FIX_LIGHT) + 1;
+    const u32 tpw = (u32)((n + ST - 1) / ST);
+    const u32 hbins = W * lb;
+    const bool on_dev = flags & DVN_MSM_SCALARS_ON_DEVICE;
+
+    CarverSize cs;
+    constexpr size_t SB = ScalarOf<Cv>::S::EW * 4;       // bytes per scalar
+    if (!on_dev) cs.take(n * SB);
+    cs.take(total * 2); cs.take(total * 4); cs.take(total * 2); cs.take(total * 4);      // digits, p1_ref, p1_lo, sorted
+    cs.take((size_t)W * tpw * lb * 4); cs.take((size_t)(3 * hbins + 4) * 4);             // hist1; bin_total, bin_base, piece_base
+    cs.take((size_t)vb * 4 * 3); cs.take(16);                                            // counts, cursor, offsets
+    cs.take((size_t)heavy_cap * 4);
+    cs.take((size_t)giant_cap * 4); cs.take((size_t)giant_cap * GIANT_PIECES * Cv::XW * 4);
+    cs.take((size_t)vb * Cv::XW * 4);
+    cs.take((size_t)nseg * Cv::XW * 4); cs.take((size_t)nseg * Cv::XW * 4);
+    cs.take((size_t)W * bpw * Cv::XW * 4); cs.take((size_t)W * Cv::XW * 4);
+    TRY(lane_ensure_ws(L, cs.off + 8192));
+    Carver cv(L.ws);
+    const u32* d_scalars;
+    if (!on_dev) {
+        u32* tmp = cv.take<u32>(n * (SB / 4));
+        HIP_TRY(hipMemcpy(tmp, scalars, n * SB, hipMemcpyHostToDevice));   // caller's buffer is free on return (cgo rule)
+        d_scalars = tmp;
+    } else d_scalars = (const u32*)scalars;
+    int16_t* digits = cv.take<int16_t>(total);
+    u32* p1_ref = cv.take<u32>(total);
+    unsigned short* p1_lo = cv.take<unsigned short>(total);
+    u32* sorted = cv.take<u32>(total);
+    u32* hist1 = cv.take<u32>((size_t)W * tpw * lb);
+    u32* bin_total = cv.take<u32>(3 * hbins + 4);
+    u32* bin_base = bin_total + hbins;                                 // hbins + 1 entries
+    u32* piece_base = bin_base + hbins + 1;                            // hbins + 1 entries
+    u32* counts = cv.take<u32>((size_t)vb * 3);
+    u32* cursor = counts + vb;
+    u32* offsets = cursor + vb;
+    u32* totals = cv.take<u32>(4);
+    u32* heavy_count = totals + 1;
+    u32* giant_count = totals + 2;
+    u32* heavy_list = cv.take<u32>(heavy_cap);
+    u32* giant_list = cv.take<u32>(giant_cap);
+    u32* giant_part = cv.take<u32>((size_t)giant_cap * GIANT_PIECES * Cv::XW);
+    u32* buckets = cv.take<u32>((size_t)vb * Cv::XW);
+    const u32 max_pieces = (u32)(total / ST) + hbins;
+    u32* edge_first = cv.take<u32>((size_t)nseg * Cv::XW);
+    u32* edge_last = cv.take<u32>((size_t)nseg * Cv::XW);
+    u32* partials = cv.take<u32>((size_t)W * bpw * Cv::XW);
+    u32* wsums = cv.take<u32>((size_t)W * Cv::XW);
+
+    hipStream_t st = L.stream;
+    static const bool dbg = getenv("DVN_DEBUG_SYNC") != nullptr;
+#define DBG_SYNC(name) do { if (dbg) { hipError_t _e = hipStreamSynchronize(st); fprintf(stderr, "[dvn] %s: %s\n", name, hipGetErrorString(_e)); fflush(stderr); if (_e != hipSuccess) return fail(DVN_ERR_DEVICE, "%s: %s", name, hipGetErrorString(_e)); } } while (0)
+    if (dbg) { fprintf(stderr, "[dvn] msm(staged) n=%zu c=%u W=%u nb=%u lob=%u lb=%u seg=%u nseg=%u tpw=%u ws=%zu\n", n, c, W, nb, lob, lb, seg, nseg, tpw, cs.off); fflush(stderr); }
+    TRY(sort_attrs<int16_t>());
+    HIP_TRY(hipEventRecord(L.ev[0], st));
+    HIP_TRY(hipMemsetAsync(totals, 0, 16, st));
+    k_digits16<typename ScalarOf<Cv>::S><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_scalars, n, c, win_lo, win_hi, digits);
+    DBG_SYNC("k_digits16");
+    k_s1_hist<int16_t><<<W * tpw, 1024, (size_t)lb * 4, st>>>(digits, n, tpw, lob, lb, hist1);
+    DBG_SYNC("k_s1_hist");
+    k_s1_offsets<<<hbins, 256, 0, st>>>(hist1, bin_total, lb, tpw);
+    DBG_SYNC("k_s1_offsets");
+    k_p1_scan<<<1, 1024, 0, st>>>(bin_total, bin_base, totals, hbins);
+    DBG_SYNC("k_p1_scan");
+    k_s1_scatter<int16_t><<<W * tpw, 1024, s1_lds(lb), st>>>(digits, n, tpw, 1u, lob, lb, 0u, 0u, win_lo, hist1, bin_base, p1_ref, p1_lo);
+    DBG_SYNC("k_s1_scatter");
+    HIP_TRY(hipMemsetAsync(counts, 0, (size_t)vb * 8, st));             // counts + cursor
+    k_s2_pieces<<<1, 1024, 0, st>>>(bin_base, hbins, piece_base);
+    DBG_SYNC("k_s2_pieces");
+    k_s2_count<<<max_pieces, 1024, 0, st>>>(bin_base, piece_base, hbins, p1_lo, lob, counts);
+    DBG_SYNC("k_s2_count");
+    k_s2_scatter<<<max_pieces, 1024, s2_lds(), st>>>(bin_base, piece_base, hbins, p1_ref, p1_lo, lob, counts, cursor, sorted, offsets);
+    DBG_SYNC("k_s2_scatter");
+    HIP_TRY(hipEventRecord(L.ev[2], st));
+    k_accumulate<Cv><<<(unsigned)(((size_t)nseg + 127) / 128), 128, 0, st>>>(pts->d, off, sorted, offsets, counts, totals, buckets,
+                                                                          edge_first, edge_last, total, vb, seg, nseg, 1);
+    DBG_SYNC("k_accumulate");
+    HIP_TRY(hipEventRecord(L.ev[3], st));
+    k_fix<Cv><<<(unsigned)(((size_t)vb + 127) / 128), 128, 0, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list,
+                                                                 heavy_count, 1, vb, seg, nseg, heavy_cap);
+    DBG_SYNC("k_fix");
+    const size_t sh_bytes = (size_t)256 * Cv::XW * 4;
+    k_fix_heavy<Cv><<<512, 256, sh_bytes, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list, heavy_count, vb, seg, nseg, heavy_cap,
+                                                giant_list, giant_count, giant_cap, GiantOk<Cv>::value ? giant_threshold() : 0xffffffffu);
+    DBG_SYNC("k_fix_heavy");
+    if constexpr (GiantOk<Cv>::value) {
+        k_giant_partial<Cv><<<1024, 256, sh_bytes, st>>>(offsets, counts, edge_first, edge_last, giant_list, giant_count, giant_cap, vb, seg, nseg, giant_part);
+        k_giant_final<Cv><<<64, GIANT_PIECES, (size_t)GIANT_PIECES * Cv::XW * 4, st>>>(giant_list, giant_count, giant_cap, giant_part, buckets);
+        DBG_SYNC("k_giant");
+    }
+    k_bucket_reduce<Cv><<<W * bpw, 256, sh_bytes, st>>>(buckets, partials, nb, LB8, bpw);
+    DBG_SYNC("k_bucket_reduce");
+    k_window_finalize<Cv><<<W, 64, (size_t)64 * Cv::XW * 4, st>>>(partials, wsums, W, bpw);
+    DBG_SYNC("k_window_finalize");
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(L.ev[1], st));
+    if ((size_t)W * Cv::XW > DVN_HSUMS_WORDS) return fail(DVN_ERR_INVALID_ARG, "too many windows for the result buffer");
+    HIP_TRY(hipMemcpyAsync(L.h_sums, wsums, (size_t)W * Cv::XW * 4, hipMemcpyDeviceToHost, st));
+    return DVN_OK;
+}
+
 template <class Cv>
 static int32_t msm_windows(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
                            u32 c, u32 nwin, u32 win_lo, u32 win_hi) {
     const u32 W = win_hi - win_lo;
+    {   // DVN_MSM_SORT=tile keeps the one-pass LDS-histogram tile sort (A/B switch)
+        static const bool tile_sort = []() { const char* v = getenv("DVN_MSM_SORT"); return v && !strcmp(v, "tile"); }();
+        if (!tile_sort) return msm_windows_staged<Cv>(ctx, L, pts, off, n, scalars, flags, c, win_lo, win_hi);
+    }
     const u32 nb = 1u << (c - 1);
     const u32 seg = pick_segment<Cv>((size_t)n * W);
     const u32 nseg = (u32)((n + seg - 1) / seg);
     const u32 LB8 = 8;                                             // buckets per thread in the reduction (latency-bound: keep chains short)
     const u32 bpw = (nb + 256 * LB8 - 1) / (256 * LB8);                // reduction blocks per window
     const u32 heavy_cap = (u32)(((size_t)W * nseg) / (FIX_LIGHT - 1) + 1);
+    const u32 giant_cap = heavy_cap / (FIX_GIANT / FIX_LIGHT) + 1;
     const bool on_dev = flags & DVN_MSM_SCALARS_ON_DEVICE;
 
     const u32 tile_len = 65536;
@@ -182,8 +325,9 @@ static int32_t msm_windows(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, size
     if (!on_dev) cs.take(n * SB);
     cs.take((size_t)W * n * 2); cs.take((size_t)W * n * 4);          // digits (int16), sorted
     cs.take((size_t)W * ntiles * nb * 4);                             // per-tile histograms
-    cs.take((size_t)W * nb * 4 * 2); cs.take((size_t)W * 4 + 4);      // counts, offsets; totals + heavy_count
+    cs.take((size_t)W * nb * 4 * 2); cs.take((size_t)W * 4 + 8);      // counts, offsets; totals + heavy_count + giant_count
     cs.take((size_t)heavy_cap * 4);
+    cs.take((size_t)giant_cap * 4); cs.take((size_t)giant_cap * GIANT_PIECES * Cv::XW * 4);
     cs.take((size_t)W * nb * Cv::XW * 4);                             // bucket sums
     cs.take((size_t)W * nseg * Cv::XW * 4); cs.take((size_t)W * nseg * Cv::XW * 4);   // edges
     cs.take((size_t)W * bpw * Cv::XW * 4); cs.take((size_t)W * Cv::XW * 4);
@@ -200,9 +344,12 @@ static int32_t msm_windows(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, size
     u32* hist = cv.take<u32>((size_t)W * ntiles * nb);
     u32* counts = cv.take<u32>((size_t)W * nb * 2);
     u32* offsets = counts + (size_t)W * nb;
-    u32* totals = cv.take<u32>(W + 1);
+    u32* totals = cv.take<u32>(W + 2);
     u32* heavy_count = totals + W;
+    u32* giant_count = totals + W + 1;
     u32* heavy_list = cv.take<u32>(heavy_cap);
+    u32* giant_list = cv.take<u32>(giant_cap);
+    u32* giant_part = cv.take<u32>((size_t)giant_cap * GIANT_PIECES * Cv::XW);
     u32* buckets = cv.take<u32>((size_t)W * nb * Cv::XW);
     u32* edge_first = cv.take<u32>((size_t)W * nseg * Cv::XW);
     u32* edge_last = cv.take<u32>((size_t)W * nseg * Cv::XW);
@@ -211,7 +358,6 @@ static int32_t msm_windows(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, size
 
     hipStream_t st = L.stream;
     static const bool dbg = getenv("DVN_DEBUG_SYNC") != nullptr;
-#define DBG_SYNC(name) do { if (dbg) { hipError_t _e = hipStreamSynchronize(st); fprintf(stderr, "[dvn] %s: %s\n", name, hipGetErrorString(_e)); fflush(stderr); if (_e != hipSuccess) return fail(DVN_ERR_DEVICE, "%s: %s", name, hipGetErrorString(_e)); } } while (0)
     if (dbg) { fprintf(stderr, "[dvn] msm n=%zu c=%u W=%u nb=%u seg=%u nseg=%u bpw=%u ntiles=%u ws=%zu\n", n, c, W, nb, seg, nseg, bpw, ntiles, cs.off); fflush(stderr); }
     const size_t hist_lds = (size_t)nb * 4;
     static bool lds_attr_set = false;
@@ -221,7 +367,7 @@ static int32_t msm_windows(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, size
         lds_attr_set = true;
     }
     HIP_TRY(hipEventRecord(L.ev[0], st));
-    HIP_TRY(hipMemsetAsync(totals, 0, (size_t)(W + 1) * 4, st));
+    HIP_TRY(hipMemsetAsync(totals, 0, (size_t)(W + 2) * 4, st));
     k_digits16<typename ScalarOf<Cv>::S><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_scalars, n, c, win_lo, win_hi, digits);
     DBG_SYNC("k_digits16");
     k_tile_hist<<<W * ntiles, 1024, hist_lds, st>>>(digits, n, nb, tile_len, ntiles, hist);
@@ -241,8 +387,14 @@ static int32_t msm_windows(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, size
                                                                      heavy_count, W, nb, seg, nseg, heavy_cap);
     DBG_SYNC("k_fix");
     const size_t sh_bytes = (size_t)256 * Cv::XW * 4;
-    k_fix_heavy<Cv><<<512, 256, sh_bytes, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list, heavy_count, nb, seg, nseg, heavy_cap);
+    k_fix_heavy<Cv><<<512, 256, sh_bytes, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list, heavy_count, nb, seg, nseg, heavy_cap,
+                                                giant_list, giant_count, giant_cap, GiantOk<Cv>::value ? giant_threshold() : 0xffffffffu);
     DBG_SYNC("k_fix_heavy");
+    if constexpr (GiantOk<Cv>::value) {
+        k_giant_partial<Cv><<<1024, 256, sh_bytes, st>>>(offsets, counts, edge_first, edge_last, giant_list, giant_count, giant_cap, nb, seg, nseg, giant_part);
+        k_giant_final<Cv><<<64, GIANT_PIECES, (size_t)GIANT_PIECES * Cv::XW * 4, st>>>(giant_list, giant_count, giant_cap, giant_part, buckets);
+        DBG_SYNC("k_giant");
+    }
     k_bucket_reduce<Cv><<<W * bpw, 256, sh_bytes, st>>>(buckets, partials, nb, LB8, bpw);
     DBG_SYNC("k_bucket_reduce");
     k_window_finalize<Cv><<<W, 64, (size_t)64 * Cv::XW * 4, st>>>(partials, wsums, W, bpw);
@@ -266,7 +418,9 @@ template <class Cv>
 static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
                             u32 win_lo, u32 win_hi) {
     const u32 c = pts->expand_c, W = win_hi - win_lo;
-    const u32 nb = 1u << (c - 1), hb = nb >> LOB;
+    const u32 nb = 1u << (c - 1);
+    const u32 lob = (c - 1 + 1) / 2 < 10 ? (c - 1 + 1) / 2 : 10, lb = nb >> lob;        // balanced split of the bucket bits
+    if (lb > 1024) return fail(DVN_ERR_INVALID_ARG, "expanded window size %u too large for the two-pass sort", c);
     const size_t total = (size_t)W * n;                              // upper bound on the number of entries
     if (total >= ((size_t)1 << 31) || (size_t)pts->nexp * pts->n >= ((size_t)1 << 31)) return fail(DVN_ERR_INVALID_ARG, "MSM too large for 31-bit entry references");
     const u32 seg = pick_segment<Cv>(total);
@@ -274,17 +428,19 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
     const u32 LB8 = 8;
     const u32 bpw = (nb + 256 * LB8 - 1) / (256 * LB8);
     const u32 heavy_cap = (u32)(nseg / (FIX_LIGHT - 1) + 1);
-    const u32 tile_len = 65536;
-    const u32 ntiles = (u32)((total + tile_len - 1) / tile_len);
+    const u32 giant_cap = heavy_cap / (FIX_GIANT / FIX_LIGHT) + 1;
+    const u32 tpw = (u32)((n + ST - 1) / ST);
+    const u32 max_pieces = (u32)(total / ST) + lb;
     const bool on_dev = flags & DVN_MSM_SCALARS_ON_DEVICE;
 
     CarverSize cs;
     constexpr size_t SB = ScalarOf<Cv>::S::EW * 4;       // bytes per scalar
     if (!on_dev) cs.take(n * SB);
     cs.take(total * 4); cs.take(total * 4); cs.take(total * 2); cs.take(total * 4);    // digits, p1_ref, p1_lo, sorted
-    cs.take((size_t)ntiles * hb * 4); cs.take((size_t)(2 * hb + 2) * 4);                 // hist1; bin_total, bin_base
-    cs.take((size_t)nb * 4 * 2); cs.take(16);                                            // counts, offsets; totals + heavy_count
+    cs.take((size_t)W * tpw * lb * 4); cs.take((size_t)(3 * lb + 4) * 4);                // hist1; bin_total, bin_base, piece_base
+    cs.take((size_t)nb * 4 * 3); cs.take(16);                                            // counts, cursor, offsets; totals + heavy_count
     cs.take((size_t)heavy_cap * 4);
+    cs.take((size_t)giant_cap * 4); cs.take((size_t)giant_cap * GIANT_PIECES * Cv::XW * 4);
     cs.take((size_t)nb * Cv::XW * 4);
     cs.take((size_t)nseg * Cv::XW * 4); cs.take((size_t)nseg * Cv::XW * 4);
     cs.take((size_t)bpw * Cv::XW * 4); cs.take((size_t)Cv::XW * 4);
@@ -300,14 +456,19 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
     u32* p1_ref = cv.take<u32>(total);
     unsigned short* p1_lo = cv.take<unsigned short>(total);
     u32* sorted = cv.take<u32>(total);
-    u32* hist1 = cv.take<u32>((size_t)ntiles * hb);
-    u32* bin_total = cv.take<u32>(2 * hb + 2);
-    u32* bin_base = bin_total + hb;
-    u32* counts = cv.take<u32>((size_t)nb * 2);
-    u32* offsets = counts + nb;
+    u32* hist1 = cv.take<u32>((size_t)W * tpw * lb);
+    u32* bin_total = cv.take<u32>(3 * lb + 4);
+    u32* bin_base = bin_total + lb;
+    u32* piece_base = bin_base + lb + 1;
+    u32* counts = cv.take<u32>((size_t)nb * 3);
+    u32* cursor = counts + nb;
+    u32* offsets = cursor + nb;
     u32* totals = cv.take<u32>(4);
     u32* heavy_count = totals + 1;
+    u32* giant_count = totals + 2;
     u32* heavy_list = cv.take<u32>(heavy_cap);
+    u32* giant_list = cv.take<u32>(giant_cap);
+    u32* giant_part = cv.take<u32>((size_t)giant_cap * GIANT_PIECES * Cv::XW);
     u32* buckets = cv.take<u32>((size_t)nb * Cv::XW);
     u32* edge_first = cv.take<u32>((size_t)nseg * Cv::XW);
     u32* edge_last = cv.take<u32>((size_t)nseg * Cv::XW);
@@ -316,21 +477,27 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
 
     hipStream_t st = L.stream;
     static const bool dbg = getenv("DVN_DEBUG_SYNC") != nullptr;
-    if (dbg) { fprintf(stderr, "[dvn] msm(expanded) n=%zu c=%u W=%u nb=%u hb=%u seg=%u nseg=%u ntiles=%u ws=%zu\n", n, c, W, nb, hb, seg, nseg, ntiles, cs.off); fflush(stderr); }
+    if (dbg) { fprintf(stderr, "[dvn] msm(expanded) n=%zu c=%u W=%u nb=%u lob=%u lb=%u seg=%u nseg=%u tpw=%u ws=%zu\n", n, c, W, nb, lob, lb, seg, nseg, tpw, cs.off); fflush(stderr); }
+    TRY(sort_attrs<int>());
     HIP_TRY(hipEventRecord(L.ev[0], st));
     HIP_TRY(hipMemsetAsync(totals, 0, 16, st));
     k_digits32<typename ScalarOf<Cv>::S><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_scalars, n, c, win_lo, win_hi, digits);
     DBG_SYNC("k_digits32");
-    k_p1_hist<<<ntiles, 1024, (size_t)hb * 4, st>>>(digits, total, tile_len, hb, hist1);
-    DBG_SYNC("k_p1_hist");
-    k_p1_offsets<<<hb, 1024, 0, st>>>(hist1, bin_total, hb, ntiles);
-    DBG_SYNC("k_p1_offsets");
-    k_p1_scan<<<1, 1024, 0, st>>>(bin_total, bin_base, totals, hb);
+    k_s1_hist<int><<<W * tpw, 1024, (size_t)lb * 4, st>>>(digits, n, tpw, lob, lb, hist1);
+    DBG_SYNC("k_s1_hist");
+    k_s1_offsets<<<lb, 256, 0, st>>>(hist1, bin_total, lb, W * tpw);
+    DBG_SYNC("k_s1_offsets");
+    k_p1_scan<<<1, 1024, 0, st>>>(bin_total, bin_base, totals, lb);
     DBG_SYNC("k_p1_scan");
-    k_p1_scatter<<<ntiles, 1024, (size_t)hb * 4, st>>>(digits, total, n, tile_len, hb, win_lo, (u32)pts->n, (u32)off, hist1, bin_base, p1_ref, p1_lo);
-    DBG_SYNC("k_p1_scatter");
-    k_p2_sort<<<hb, 1u << LOB, 0, st>>>(bin_base, p1_ref, p1_lo, sorted, counts, offsets);
-    DBG_SYNC("k_p2_sort");
+    k_s1_scatter<int><<<W * tpw, 1024, s1_lds(lb), st>>>(digits, n, tpw, 0u, lob, lb, (u32)off, (u32)pts->n, win_lo, hist1, bin_base, p1_ref, p1_lo);
+    DBG_SYNC("k_s1_scatter");
+    HIP_TRY(hipMemsetAsync(counts, 0, (size_t)nb * 8, st));             // counts + cursor
+    k_s2_pieces<<<1, 1024, 0, st>>>(bin_base, lb, piece_base);
+    DBG_SYNC("k_s2_pieces");
+    k_s2_count<<<max_pieces, 1024, 0, st>>>(bin_base, piece_base, lb, p1_lo, lob, counts);
+    DBG_SYNC("k_s2_count");
+    k_s2_scatter<<<max_pieces, 1024, s2_lds(), st>>>(bin_base, piece_base, lb, p1_ref, p1_lo, lob, counts, cursor, sorted, offsets);
+    DBG_SYNC("k_s2_scatter");
     HIP_TRY(hipEventRecord(L.ev[2], st));
     k_accumulate<Cv><<<(unsigned)(((size_t)nseg + 127) / 128), 128, 0, st>>>(pts->d, 0, sorted, offsets, counts, totals, buckets,
                                                                           edge_first, edge_last, total, nb, seg, nseg, 1);
@@ -340,8 +507,14 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
                                                                  heavy_count, 1, nb, seg, nseg, heavy_cap);
     DBG_SYNC("k_fix");
     const size_t sh_bytes = (size_t)256 * Cv::XW * 4;
-    k_fix_heavy<Cv><<<512, 256, sh_bytes, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list, heavy_count, nb, seg, nseg, heavy_cap);
+    k_fix_heavy<Cv><<<512, 256, sh_bytes, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list, heavy_count, nb, seg, nseg, heavy_cap,
+                                                giant_list, giant_count, giant_cap, GiantOk<Cv>::value ? giant_threshold() : 0xffffffffu);
     DBG_SYNC("k_fix_heavy");
+    if constexpr (GiantOk<Cv>::value) {
+        k_giant_partial<Cv><<<1024, 256, sh_bytes, st>>>(offsets, counts, edge_first, edge_last, giant_list, giant_count, giant_cap, nb, seg, nseg, giant_part);
+        k_giant_final<Cv><<<64, GIANT_PIECES, (size_t)GIANT_PIECES * Cv::XW * 4, st>>>(giant_list, giant_count, giant_cap, giant_part, buckets);
+        DBG_SYNC("k_giant");
+    }
     k_bucket_reduce<Cv><<<bpw, 256, sh_bytes, st>>>(buckets, partials, nb, LB8, bpw);
     DBG_SYNC("k_bucket_reduce");
     k_window_finalize<Cv><<<1, 64, (size_t)64 * Cv::XW * 4, st>>>(partials, wsum, 1, bpw);
@@ -354,7 +527,7 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
 
 // (re)build the expanded table of an existing set for window size c (0 = back to a plain set)
 template <class Cv> static int32_t points_set_expanded(dvn_ctx* ctx, dvn_points* p, u32 c) {
-    if (c != 0 && (c < 11 || c > 24)) return fail(DVN_ERR_INVALID_ARG, "window_bits must be 0 or in [11, 24]");
+    if (c != 0 && (c < 11 || c > 21)) return fail(DVN_ERR_INVALID_ARG, "window_bits must be 0 or in [11, 21]");
     const u32 nexp = c ? ScalarOf<Cv>::S::BITS / c + 1 : 1;
     if ((size_t)nexp * p->n >= ((size_t)1 << 31)) return fail(DVN_ERR_INVALID_ARG, "expanded table too large");
     HIP_TRY(hipStreamSynchronize(ctx->stream));

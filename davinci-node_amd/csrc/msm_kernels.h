@@ -249,10 +249,8 @@ static __global__ void k_scan(const u32* __restrict__ counts, u32* __restrict__ 
 // is widened to rows  row_w[i] = 2^(c w) * P_i,  w < nexp.  Every window of every scalar then lands in the SAME
 // 2^(c-1) buckets, so window size is no longer tied to the bucket-reduction cost: c = 20 gives 13 windows instead of
 // 16 (19 % fewer mixed additions), one bucket reduction instead of 16 and no window combine at all.
-// Sorting 2^19 buckets no longer fits an LDS histogram: two passes -- by the high bits of the bucket (LDS histogram of
-// <= 2048 bins per 64K-entry tile), then one block per high-bits bin sorts its contiguous segment by the low 10 bits.
+// Sorting 2^19 buckets no longer fits an LDS histogram: the two-pass staged sort below splits the bucket bits evenly.
 // ====================================================================================================================
-constexpr u32 LOB = 10;                       // low bucket bits sorted in pass 2 (2^LOB threads per pass-2 block)
 template <class Cv> __global__ void k_points_expand(u32* __restrict__ table, size_t n, u32 c, u32 nexp) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -297,40 +295,6 @@ template <class S> __global__ void k_digits32(const u32* __restrict__ scalars, s
         if (win >= win_lo) digits[(size_t)(win - win_lo) * n + i] = v;
     }
 }
-// pass 1, block = tile of the flattened (window, point) entry space: histogram over the high bucket bits
-static __global__ __launch_bounds__(1024) void k_p1_hist(const int* __restrict__ digits, size_t total, u32 tile_len, u32 hb,
-                                                         u32* __restrict__ hist1) {
-    extern __shared__ __align__(16) u32 lh[];
-    for (u32 b = threadIdx.x; b < hb; b += blockDim.x) lh[b] = 0;
-    __syncthreads();
-    const size_t lo = (size_t)blockIdx.x * tile_len, hi = min(lo + (size_t)tile_len, total);
-    for (size_t g = lo + threadIdx.x; g < hi; g += blockDim.x) {
-        const int d = digits[g];
-        if (d) atomicAdd(&lh[((u32)(d < 0 ? -d : d) - 1) >> LOB], 1u);
-    }
-    __syncthreads();
-    for (u32 b = threadIdx.x; b < hb; b += blockDim.x) hist1[(size_t)blockIdx.x * hb + b] = lh[b];
-}
-// block = high bin: exclusive prefix of hist1 over the tiles (in place), bin_total[bin]
-static __global__ __launch_bounds__(1024) void k_p1_offsets(u32* __restrict__ hist1, u32* __restrict__ bin_total, u32 hb, u32 ntiles) {
-    __shared__ u32 part[1024];
-    const u32 bin = blockIdx.x, t = threadIdx.x, T = blockDim.x;
-    const u32 per = (ntiles + T - 1) / T;
-    const u32 lo = t * per, hi = min(lo + per, ntiles);
-    u32 s = 0;
-    for (u32 k = lo; k < hi; ++k) s += hist1[(size_t)k * hb + bin];
-    part[t] = s;
-    __syncthreads();
-    for (u32 d = 1; d < T; d <<= 1) {
-        u32 v = (t >= d) ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    u32 run = part[t] - s;
-    for (u32 k = lo; k < hi; ++k) { const u32 v = hist1[(size_t)k * hb + bin]; hist1[(size_t)k * hb + bin] = run; run += v; }
-    if (t == T - 1) bin_total[bin] = part[t];
-}
 // single block: bin_base = exclusive scan of bin_total (hb <= 2048), bin_base[hb] = totals[0] = number of entries
 static __global__ __launch_bounds__(1024) void k_p1_scan(const u32* __restrict__ bin_total, u32* __restrict__ bin_base,
                                                          u32* __restrict__ totals, u32 hb) {
@@ -352,58 +316,208 @@ static __global__ __launch_bounds__(1024) void k_p1_scan(const u32* __restrict__
     for (u32 k = lo; k < hi; ++k) { bin_base[k] = run; run += bin_total[k]; }
     if (t == T - 1) { bin_base[hb] = part[t]; totals[0] = part[t]; }
 }
-// pass 1 scatter: entry (w, i) -> position inside its high bin; carries ref = row * stride + point | sign and the low bits
-static __global__ __launch_bounds__(1024) void k_p1_scatter(const int* __restrict__ digits, size_t total, size_t n, u32 tile_len,
-                                                            u32 hb, u32 win_lo, u32 row_stride, u32 pts_off,
-                                                            const u32* __restrict__ hist1, const u32* __restrict__ bin_base,
-                                                            u32* __restrict__ p1_ref, unsigned short* __restrict__ p1_lo) {
-    extern __shared__ __align__(16) u32 lh[];
-    for (u32 b = threadIdx.x; b < hb; b += blockDim.x) lh[b] = bin_base[b] + hist1[(size_t)blockIdx.x * hb + b];
+// ====================================================================================================================
+// Two-pass LDS-staged sort: the scattered 4-byte stores of a one-pass counting sort leave L2 as one
+// request each (2^26 requests per 2^22-point MSM, ~1.3 ms), so both passes here reorder their tile in LDS first and
+// write RUNS: consecutive lanes store consecutive addresses.
+//   pass 1  tile = ST consecutive points of one window: bin = bucket >> lob (lb = nb >> lob bins per key-window),
+//           LDS histogram -> ranks, LDS reorder by bin, coalesced copy-out of (ref, low bits) into the bin's segment
+//   pass 2  block = one bin: counts its 2^lob sub-buckets (emits the per-bucket counts/offsets the accumulate kernel
+//           needs), then sorts the segment chunk by chunk through LDS the same way.
+// Keys: key = kw * nb + bucket, kw = the window for plain sets ("keyed"), 0 for expanded sets (one bucket set).
+// ====================================================================================================================
+constexpr u32 ST = 8192;                       // entries per pass-1 tile and per pass-2 chunk (8 per thread)
+// exclusive prefix of v over the block (1024 threads); *total = block sum.  wsum: >= 80 words of LDS.  The caller
+// separates two calls by a __syncthreads().
+__device__ __forceinline__ u32 block_excl_scan(u32 v, u32* wsum, u32* total) {
+    const u32 lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    u32 inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d, 64); if (lane >= (u32)d) inc += o; }
+    if (lane == 63) wsum[wid] = inc;
     __syncthreads();
-    const size_t lo = (size_t)blockIdx.x * tile_len, hi = min(lo + (size_t)tile_len, total);
-    for (size_t g = lo + threadIdx.x; g < hi; g += blockDim.x) {
-        const int d = digits[g];
+    if (wid == 0) {
+        const u32 sv = lane < (blockDim.x >> 6) ? wsum[lane] : 0;
+        u32 si = sv;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(si, d, 64); if (lane >= (u32)d) si += o; }
+        wsum[lane] = si - sv;
+        if (lane == 63) wsum[64] = si;
+    }
+    __syncthreads();
+    *total = wsum[64];
+    return wsum[wid] + inc - v;
+}
+template <class D> __device__ __forceinline__ u32 digit_bucket(D d) { const int v = (int)d; return (u32)(v < 0 ? -v : v) - 1; }
+
+// pass 1a, block = tile (w, t): histogram of the tile over its key-window's lb bins
+template <class D> __global__ __launch_bounds__(1024) void k_s1_hist(const D* __restrict__ digits, size_t n, u32 tpw, u32 lob, u32 lb,
+                                                                   u32* __restrict__ hist1) {
+    extern __shared__ __align__(16) u32 sm[];
+    const u32 w = blockIdx.x / tpw, t = blockIdx.x % tpw;
+    for (u32 b = threadIdx.x; b < lb; b += blockDim.x) sm[b] = 0;
+    __syncthreads();
+    const size_t lo = (size_t)t * ST;
+    const u32 cnt = (u32)min((size_t)ST, n - lo);
+    const D* dg = digits + (size_t)w * n + lo;
+    for (u32 e = threadIdx.x; e < cnt; e += blockDim.x) {
+        const D d = dg[e];
+        if (d) atomicAdd(&sm[digit_bucket(d) >> lob], 1u);
+    }
+    __syncthreads();
+    for (u32 b = threadIdx.x; b < lb; b += blockDim.x) hist1[(size_t)blockIdx.x * lb + b] = sm[b];
+}
+// pass 1b, block = (kw, bin): exclusive prefix of hist1 over the tk tiles of key-window kw (in place); bin_total
+static __global__ __launch_bounds__(256) void k_s1_offsets(u32* __restrict__ hist1, u32* __restrict__ bin_total, u32 lb, u32 tk) {
+    __shared__ u32 part[256];
+    const u32 kw = blockIdx.x / lb, bin = blockIdx.x % lb, t = threadIdx.x, T = blockDim.x;
+    u32* h = hist1 + (size_t)kw * tk * lb + bin;
+    const u32 per = (tk + T - 1) / T;
+    const u32 lo = min(t * per, tk), hi = min(lo + per, tk);
+    u32 s = 0;
+    for (u32 k = lo; k < hi; ++k) s += h[(size_t)k * lb];
+    part[t] = s;
+    __syncthreads();
+    for (u32 d = 1; d < T; d <<= 1) {
+        u32 v = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    u32 run = part[t] - s;
+    for (u32 k = lo; k < hi; ++k) { const u32 v = h[(size_t)k * lb]; h[(size_t)k * lb] = run; run += v; }
+    if (t == T - 1) bin_total[blockIdx.x] = part[t];
+}
+// pass 1c: LDS-staged scatter.  LDS: lh[lb], lbase[lb], gbase[lb], wsum[80], st_ref[ST], st_aux[ST]
+template <class D> __global__ __launch_bounds__(1024) void k_s1_scatter(const D* __restrict__ digits, size_t n, u32 tpw, u32 keyed, u32 lob, u32 lb,
+                                                                      u32 ref_base, u32 row_stride, u32 win_lo,
+                                                                      const u32* __restrict__ hist1, const u32* __restrict__ bin_base,
+                                                                      u32* __restrict__ p1_ref, unsigned short* __restrict__ p1_lo) {
+    extern __shared__ __align__(16) u32 sm[];
+    u32 *lh = sm, *lbase = lh + lb, *gbase = lbase + lb, *wsum = gbase + lb, *st_ref = wsum + 80, *st_aux = st_ref + ST;
+    const u32 w = blockIdx.x / tpw, t = blockIdx.x % tpw, kw = keyed ? w : 0, tid = threadIdx.x;
+    for (u32 b = tid; b < lb; b += blockDim.x) lh[b] = 0;
+    __syncthreads();
+    const size_t lo = (size_t)t * ST;
+    const u32 cnt = (u32)min((size_t)ST, n - lo);
+    const D* dg = digits + (size_t)w * n + lo;
+    int dv[ST / 1024]; u32 rk[ST / 1024];
+#pragma unroll
+    for (u32 j = 0; j < ST / 1024; ++j) {
+        const u32 e = j * 1024 + tid;
+        const int d = e < cnt ? (int)dg[e] : 0;
+        dv[j] = d; rk[j] = 0;
+        if (d) rk[j] = atomicAdd(&lh[digit_bucket(d) >> lob], 1u);
+    }
+    __syncthreads();
+    u32 tot;
+    const u32 ex = block_excl_scan(tid < lb ? lh[tid] : 0u, wsum, &tot);          // lb <= 1024
+    if (tid < lb) { lbase[tid] = ex; gbase[tid] = bin_base[(size_t)kw * lb + tid] + hist1[(size_t)blockIdx.x * lb + tid] - ex; }
+    __syncthreads();
+    const u32 lomask = (1u << lob) - 1;
+    const u32 rbase = ref_base + (win_lo + w) * row_stride + (u32)lo;
+#pragma unroll
+    for (u32 j = 0; j < ST / 1024; ++j) {
+        const int d = dv[j];
         if (d) {
-            const u32 bucket = (u32)(d < 0 ? -d : d) - 1;
-            const u32 w = (u32)(g / n), i = (u32)(g - (size_t)w * n);
-            const u32 pos = atomicAdd(&lh[bucket >> LOB], 1u);
-            p1_ref[pos] = ((win_lo + w) * row_stride + pts_off + i) | (d < 0 ? SIGN_BIT : 0u);
-            p1_lo[pos] = (unsigned short)(bucket & ((1u << LOB) - 1));
+            const u32 bucket = digit_bucket(d), bin = bucket >> lob, slot = lbase[bin] + rk[j];
+            st_ref[slot] = (rbase + j * 1024 + tid) | (d < 0 ? SIGN_BIT : 0u);
+            st_aux[slot] = (bin << 16) | (bucket & lomask);
         }
     }
+    __syncthreads();
+    for (u32 s = tid; s < tot; s += blockDim.x) {
+        const u32 aux = st_aux[s], ga = gbase[aux >> 16] + s;
+        p1_ref[ga] = st_ref[s];
+        p1_lo[ga] = (unsigned short)aux;
+    }
 }
-// pass 2, block = high bin: counting sort of the bin's contiguous segment by the low bits; emits the per-bucket
-// counts / offsets the accumulate kernel needs
-static __global__ __launch_bounds__(1024) void k_p2_sort(const u32* __restrict__ bin_base, const u32* __restrict__ p1_ref,
-                                                         const unsigned short* __restrict__ p1_lo, u32* __restrict__ sorted,
-                                                         u32* __restrict__ counts, u32* __restrict__ offsets) {
-    __shared__ u32 cnt[1u << LOB];
-    __shared__ u32 cur[1u << LOB];
-    const u32 bin = blockIdx.x, t = threadIdx.x;           // blockDim.x == 1 << LOB
-    const u32 s0 = bin_base[bin], s1 = bin_base[bin + 1];
-    cnt[t] = 0;
+// pass 2 works on PIECES: piece = up to ST consecutive entries of one bin's segment, every bin has at least one (so
+// its offsets get written).  A skewed scalar distribution (a witness with 25 % ones puts a quarter of all entries in
+// one bucket) therefore spreads over many blocks; positions inside a bucket are claimed with one global atomic per
+// (piece, non-empty sub-bucket) -- the order of a bucket's entries is not deterministic, their sum is.
+// piece_base[bin] = first piece of bin, piece_base[hbins] = number of pieces
+static __global__ __launch_bounds__(1024) void k_s2_pieces(const u32* __restrict__ bin_base, u32 hbins, u32* __restrict__ piece_base) {
+    __shared__ u32 part[1024];
+    const u32 t = threadIdx.x, T = blockDim.x;
+    const u32 per = (hbins + T - 1) / T;
+    const u32 lo = min(t * per, hbins), hi = min(lo + per, hbins);
+    u32 s = 0;
+    for (u32 k = lo; k < hi; ++k) { const u32 len = bin_base[k + 1] - bin_base[k]; s += len ? (len + ST - 1) / ST : 1u; }
+    part[t] = s;
     __syncthreads();
-    for (u32 e = s0 + t; e < s1; e += blockDim.x) atomicAdd(&cnt[p1_lo[e]], 1u);
-    __syncthreads();
-    const u32 mine = cnt[t];
-    cur[t] = mine;
-    __syncthreads();
-    for (u32 d = 1; d < blockDim.x; d <<= 1) {
-        u32 v = (t >= d) ? cur[t - d] : 0;
+    for (u32 d = 1; d < T; d <<= 1) {
+        u32 v = (t >= d) ? part[t - d] : 0;
         __syncthreads();
-        cur[t] += v;
+        part[t] += v;
         __syncthreads();
     }
-    const u32 off = s0 + cur[t] - mine;
+    u32 run = part[t] - s;
+    for (u32 k = lo; k < hi; ++k) { const u32 len = bin_base[k + 1] - bin_base[k]; piece_base[k] = run; run += len ? (len + ST - 1) / ST : 1u; }
+    if (t == T - 1) piece_base[hbins] = part[t];
+}
+// block -> (bin, first entry, entry count) of its piece; false if the block is beyond the last piece
+__device__ __forceinline__ bool s2_piece(const u32* __restrict__ bin_base, const u32* __restrict__ piece_base, u32 hbins,
+                                         u32* bin, u32* e0, u32* cn) {
+    const u32 pc = blockIdx.x;
+    if (pc >= piece_base[hbins]) return false;
+    u32 lo = 0, hi = hbins;                   // largest bin with piece_base[bin] <= pc
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (piece_base[mid] <= pc) lo = mid; else hi = mid; }
+    const u32 s0 = bin_base[lo] + (pc - piece_base[lo]) * ST, s1 = bin_base[lo + 1];
+    *bin = lo; *e0 = s0; *cn = s1 > s0 ? min(ST, s1 - s0) : 0u;
+    return true;
+}
+// pass 2a, block = piece: sub-bucket histogram in LDS, merged into counts[] (zeroed by the host) with global atomics
+static __global__ __launch_bounds__(1024) void k_s2_count(const u32* __restrict__ bin_base, const u32* __restrict__ piece_base, u32 hbins,
+                                                          const unsigned short* __restrict__ p1_lo, u32 lob, u32* __restrict__ counts) {
+    __shared__ u32 h[1024];
+    u32 bin, e0, cn;
+    if (!s2_piece(bin_base, piece_base, hbins, &bin, &e0, &cn)) return;
+    const u32 tid = threadIdx.x;
+    h[tid] = 0;
     __syncthreads();
-    cur[t] = off;
-    counts[((size_t)bin << LOB) + t] = mine;
-    offsets[((size_t)bin << LOB) + t] = off;
+    for (u32 e = tid; e < cn; e += blockDim.x) atomicAdd(&h[p1_lo[e0 + e]], 1u);
     __syncthreads();
-    for (u32 e = s0 + t; e < s1; e += blockDim.x) {
-        const u32 pos = atomicAdd(&cur[p1_lo[e]], 1u);
-        sorted[pos] = p1_ref[e];
+    if (h[tid]) atomicAdd(&counts[((size_t)bin << lob) + tid], h[tid]);
+}
+// pass 2b, block = piece.  LDS: base[1024], h2[1024], lb2[1024], gpos[1024], wsum[80], st_ref[ST], st_sub[ST] (u16)
+static __global__ __launch_bounds__(1024) void k_s2_scatter(const u32* __restrict__ bin_base, const u32* __restrict__ piece_base, u32 hbins,
+                                                            const u32* __restrict__ p1_ref, const unsigned short* __restrict__ p1_lo, u32 lob,
+                                                            const u32* __restrict__ counts, u32* __restrict__ cursor,
+                                                            u32* __restrict__ sorted, u32* __restrict__ offsets) {
+    extern __shared__ __align__(16) u32 sm[];
+    u32 *base = sm, *h2 = base + 1024, *lb2 = h2 + 1024, *gpos = lb2 + 1024, *wsum = gpos + 1024, *st_ref = wsum + 80;
+    unsigned short* st_sub = (unsigned short*)(st_ref + ST);
+    u32 bin, e0, cn;
+    if (!s2_piece(bin_base, piece_base, hbins, &bin, &e0, &cn)) return;
+    const u32 sb = 1u << lob, tid = threadIdx.x;
+    const bool first_piece = blockIdx.x == piece_base[bin];
+    const size_t key0 = (size_t)bin << lob;
+    u32 tot;
+    const u32 ex = block_excl_scan(tid < sb ? counts[key0 + tid] : 0u, wsum, &tot);
+    base[tid] = bin_base[bin] + ex;
+    if (first_piece && tid < sb) offsets[key0 + tid] = bin_base[bin] + ex;
+    h2[tid] = 0;
+    __syncthreads();
+    u32 rf[ST / 1024], rk[ST / 1024]; unsigned short sl[ST / 1024];
+#pragma unroll
+    for (u32 j = 0; j < ST / 1024; ++j) {
+        const u32 e = j * 1024 + tid;
+        rf[j] = 0; rk[j] = 0; sl[j] = 0;
+        if (e < cn) { sl[j] = p1_lo[e0 + e]; rf[j] = p1_ref[e0 + e]; rk[j] = atomicAdd(&h2[sl[j]], 1u); }
     }
+    __syncthreads();
+    const u32 mine = h2[tid];
+    const u32 ex2 = block_excl_scan(mine, wsum, &tot);
+    lb2[tid] = ex2;
+    if (mine) gpos[tid] = base[tid] + atomicAdd(&cursor[key0 + tid], mine);
+    __syncthreads();
+#pragma unroll
+    for (u32 j = 0; j < ST / 1024; ++j) {
+        if (j * 1024 + tid < cn) { const u32 slot = lb2[sl[j]] + rk[j]; st_ref[slot] = rf[j]; st_sub[slot] = sl[j]; }
+    }
+    __syncthreads();
+    for (u32 s = tid; s < cn; s += blockDim.x) { const u32 sub = st_sub[s]; sorted[gpos[sub] + (s - lb2[sub])] = st_ref[s]; }
 }
 
 // ---- HOT KERNEL: segment accumulation -------------------------------------------------------------------
@@ -462,6 +576,7 @@ __global__ __launch_bounds__(128) void k_accumulate(const u32* __restrict__ poin
 
 // lane per bucket: empty -> infinity; spanning <= FIX_LIGHT segments -> stitch serially; more -> heavy list
 constexpr u32 FIX_LIGHT = 24;
+constexpr u32 FIX_GIANT = 1536, GIANT_PIECES = 64;      // see k_giant_partial
 template <class Cv>
 __global__ __launch_bounds__(128) void k_fix(const u32* __restrict__ offsets, const u32* __restrict__ counts,
                                              u32* __restrict__ bucket_sums, const u32* __restrict__ edge_first,
@@ -506,7 +621,8 @@ template <class Cv>
 __global__ __launch_bounds__(256) void k_fix_heavy(const u32* __restrict__ offsets, const u32* __restrict__ counts,
                                                    u32* __restrict__ bucket_sums, const u32* __restrict__ edge_first,
                                                    const u32* __restrict__ edge_last, const u32* __restrict__ heavy_list,
-                                                   const u32* __restrict__ heavy_count, u32 nb, u32 seg, u32 nseg, u32 heavy_cap) {
+                                                   const u32* __restrict__ heavy_count, u32 nb, u32 seg, u32 nseg, u32 heavy_cap,
+                                                   u32* __restrict__ giant_list, u32* __restrict__ giant_count, u32 giant_cap, u32 giant_thresh) {
     typedef typename Cv::X X;
     extern __shared__ __align__(16) u32 sh[];
     const u32 nheavy = min(*heavy_count, heavy_cap);
@@ -515,6 +631,10 @@ __global__ __launch_bounds__(256) void k_fix_heavy(const u32* __restrict__ offse
         const u32 w = g / nb;
         const u32 o = offsets[g], e = o + counts[g];
         const u32 ks = o / seg, ke = (e - 1) / seg;
+        if (ke - ks + 1 > giant_thresh) {         // a bucket of this size gets GIANT_PIECES blocks (k_giant_*)
+            if (threadIdx.x == 0) { const u32 slot = atomicAdd(giant_count, 1u); if (slot < giant_cap) giant_list[slot] = g; }
+            continue;
+        }
         const u32* first = edge_first + (size_t)w * nseg * Cv::XW;
         const u32* last = edge_last + (size_t)w * nseg * Cv::XW;
         X acc = Cv::infinity();
@@ -524,6 +644,49 @@ __global__ __launch_bounds__(256) void k_fix_heavy(const u32* __restrict__ offse
         }
         acc = block_sum<Cv>(acc, sh);
         if (threadIdx.x == 0) st_xyzz<Cv>(acc, bucket_sums + (size_t)g * Cv::XW);
+        __syncthreads();
+    }
+}
+
+// Giant buckets (more than FIX_GIANT segments: a witness with 25 % ones, or the 2-bit top window of a 254-bit scalar cut
+// into 18- or 21-bit windows, puts a quarter of ALL entries into one bucket): GIANT_PIECES blocks per bucket sum slices of
+// its segment partials, a second small kernel adds the slices up.
+template <class Cv>
+__global__ __launch_bounds__(256) void k_giant_partial(const u32* __restrict__ offsets, const u32* __restrict__ counts,
+                                                       const u32* __restrict__ edge_first, const u32* __restrict__ edge_last,
+                                                       const u32* __restrict__ giant_list, const u32* __restrict__ giant_count, u32 giant_cap,
+                                                       u32 nb, u32 seg, u32 nseg, u32* __restrict__ giant_part) {
+    typedef typename Cv::X X;
+    extern __shared__ __align__(16) u32 sh[];
+    const u32 items = min(*giant_count, giant_cap) * GIANT_PIECES;
+    for (u32 it = blockIdx.x; it < items; it += gridDim.x) {
+        const u32 g = giant_list[it / GIANT_PIECES], piece = it % GIANT_PIECES;
+        const u32 w = g / nb;
+        const u32 o = offsets[g], e = o + counts[g];
+        const u32 ks = o / seg, ke = (e - 1) / seg;
+        const u32 per = (ke - ks + GIANT_PIECES) / GIANT_PIECES;          // ceil((ke - ks + 1) / GIANT_PIECES)
+        const u32 k0 = ks + piece * per, k1 = min(k0 + per, ke + 1);
+        const u32* first = edge_first + (size_t)w * nseg * Cv::XW;
+        const u32* last = edge_last + (size_t)w * nseg * Cv::XW;
+        X acc = Cv::infinity();
+        for (u32 k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
+            const u32* src = (k == ks && (o % seg) != 0) ? last : first;
+            acc = Cv::add(acc, ld_xyzz<Cv>(src + (size_t)k * Cv::XW));
+        }
+        acc = block_sum<Cv>(acc, sh);
+        if (threadIdx.x == 0) st_xyzz<Cv>(acc, giant_part + (size_t)it * Cv::XW);
+        __syncthreads();
+    }
+}
+template <class Cv>
+__global__ __launch_bounds__(64) void k_giant_final(const u32* __restrict__ giant_list, const u32* __restrict__ giant_count, u32 giant_cap,
+                                                    const u32* __restrict__ giant_part, u32* __restrict__ bucket_sums) {
+    extern __shared__ __align__(16) u32 sh[];
+    const u32 ng = min(*giant_count, giant_cap);
+    for (u32 h = blockIdx.x; h < ng; h += gridDim.x) {             // blockDim.x == GIANT_PIECES
+        typename Cv::X acc = ld_xyzz<Cv>(giant_part + ((size_t)h * GIANT_PIECES + threadIdx.x) * Cv::XW);
+        acc = block_sum<Cv>(acc, sh);
+        if (threadIdx.x == 0) st_xyzz<Cv>(acc, bucket_sums + (size_t)giant_list[h] * Cv::XW);
         __syncthreads();
     }
 }

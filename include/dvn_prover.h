@@ -62,7 +62,7 @@ int32_t dvn_points_upload_g2(dvn_ctx* ctx, const uint64_t* xy_mont, size_t n, dv
  * SplitMix64 stream `seed`.  Bench/test input generator. */
 int32_t dvn_points_synthetic_g1(dvn_ctx* ctx, uint64_t seed, size_t n, dvn_points** out);
 int32_t dvn_points_synthetic_g2(dvn_ctx* ctx, uint64_t seed, size_t n, dvn_points** out);
-/* (Re)build the set as an expanded table for window size window_bits in [11, 24] (row w = 2^(window_bits * w) * P_i,
+/* (Re)build the set as an expanded table for window size window_bits in [11, 21] (row w = 2^(window_bits * w) * P_i,
  * 254 / window_bits + 1 rows), or collapse it back with 0.  G2 sets of >= 2^17 points are expanded
  * automatically at upload; G1 sets stay plain by default (measured: no gain). */
 int32_t dvn_points_set_expanded(dvn_ctx* ctx, dvn_points* pts, uint32_t window_bits);
