@@ -235,7 +235,7 @@ static int32_t fixed_base_points(dvn_ctx* ctx, const typename Cv::A& gen, const 
     dvn_points* p = new (std::nothrow) dvn_points();
     if (!p) return fail(DVN_ERR_OOM, "host allocation failed");
     p->curve = curve; p->n = count;
-    expand_plan(curve, count, 254, &p->expand_c, &p->nexp);
+    expand_plan(count, 254, (size_t)Cv::AW * 4, &p->expand_c, &p->nexp);
     u32 *table = nullptr, *dgen = nullptr;
     u32 hg[Cv::AW];
     Cv::store_affine_internal(gen, hg);

@@ -55,16 +55,20 @@ struct dvn_points {
     u32 expand_c = 0;         // 0 = plain set (one row); otherwise the window size the rows were built for
     u32 nexp = 1;
 };
-// Default expansion policy (measured on MI355X, tools/gpu_cmp.py): G2 sets of >= 2^17 points win 10-35 % from the
-// one-bucket-set layout (their accumulate dominates); for G1 the two-pass sort of 2^19 buckets eats the 19 % saved
-// additions, so G1 sets stay plain unless dvn_points_set_expanded is called.  DVN_MSM_EXPAND=0 disables it globally.
-static inline void expand_plan(int curve, size_t n, u32 scalar_bits, u32* c, u32* nexp) {
+// Default expansion policy (measured on MI355X, tools/gpu_expand_sweep.py, G1 and G2 alike): with the staged sort the
+// one-bucket-set layout wins 10-30 % from 2^15 points up -- window 16 below 2^18, 17 below 2^20, 20 from there (18, 19 and
+// 21 lose: their top window holds 2-7 bits of a 254-bit scalar and piles a quarter of all entries into a few buckets).
+// A set is left plain when its table would exceed DVN_MSM_EXPAND_MAX_GB (default 16 GiB; HBM is 288 GB, a Groth16 key has
+// five sets).  DVN_MSM_EXPAND=0 disables expansion globally.
+static inline void expand_plan(size_t n, u32 scalar_bits, size_t point_bytes, u32* c, u32* nexp) {
     static const int enabled = []() { const char* v = getenv("DVN_MSM_EXPAND"); return (v && v[0] == '0') ? 0 : 1; }();
+    static const size_t max_bytes = []() { const char* v = getenv("DVN_MSM_EXPAND_MAX_GB"); return (size_t)(v ? atoi(v) : 16) << 30; }();
     *c = 0; *nexp = 1;
-    if (!enabled || curve != 2) return;
-    if (n >= ((size_t)1 << 19)) *c = 20;
-    else if (n >= ((size_t)1 << 17)) *c = 18;
-    if (*c) *nexp = scalar_bits / *c + 1;
+    if (!enabled || n < ((size_t)1 << 15)) return;
+    const u32 cc = n >= ((size_t)1 << 20) ? 20 : n >= ((size_t)1 << 18) ? 17 : 16;
+    const u32 rows = scalar_bits / cc + 1;
+    if ((size_t)rows * n * point_bytes > max_bytes || (size_t)rows * n >= ((size_t)1 << 31)) return;
+    *c = cc; *nexp = rows;
 }
 struct dvn_domain {
     int suite = 0;            // 0 = BN254 Fr, 1 = BLS12-377 Fr

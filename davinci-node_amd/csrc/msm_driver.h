@@ -22,8 +22,6 @@ template <> struct ScalarOf<G_761> { typedef Fp377Cfg S; };                     
 template <> struct SuiteOf<G_761> { static constexpr int value = 2; };               // 2 = BW6-761
 template <class F> struct IsQuadratic { static constexpr bool value = false; };
 template <class C> struct IsQuadratic<Fe2<C>> { static constexpr bool value = true; };
-// expanded point sets are planned for G2 over a quadratic extension only (BW6-761's G2 lives over the base field)
-template <class Cv> static inline int plan_curve(int curve) { return (curve == 2 && !IsQuadratic<typename Cv::O::F>::value) ? 1 : curve; }
 
 // ------------------------------------------------------------------------------------------------------
 // points
@@ -37,7 +35,7 @@ template <class Cv> static int32_t points_upload(dvn_ctx* ctx, const uint64_t* x
     if (!p) return fail(DVN_ERR_OOM, "host allocation failed");
     p->curve = curve; p->n = n;
     p->suite = SuiteOf<Cv>::value;
-    expand_plan(plan_curve<Cv>(curve), n, ScalarOf<Cv>::S::BITS, &p->expand_c, &p->nexp);
+    expand_plan(n, ScalarOf<Cv>::S::BITS, (size_t)Cv::AW * 4, &p->expand_c, &p->nexp);
     size_t bytes = n * Cv::AW * 4;
     hipError_t e = hipMalloc((void**)&p->d, bytes ? bytes * p->nexp : 16);
     if (e != hipSuccess) { delete p; (void)hipGetLastError(); return fail(DVN_ERR_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
@@ -63,7 +61,7 @@ template <class Cv> static int32_t points_progression(dvn_ctx* ctx, size_t n, in
     if (!p) return fail(DVN_ERR_OOM, "host allocation failed");
     p->curve = curve; p->n = n;
     p->suite = SuiteOf<Cv>::value;
-    expand_plan(plan_curve<Cv>(curve), n, ScalarOf<Cv>::S::BITS, &p->expand_c, &p->nexp);
+    expand_plan(n, ScalarOf<Cv>::S::BITS, (size_t)Cv::AW * 4, &p->expand_c, &p->nexp);
     u32* dbs = nullptr;
     hipError_t e = hipMalloc((void**)&p->d, n ? n * Cv::AW * 4 * p->nexp : 16);
     if (e == hipSuccess) e = hipMalloc((void**)&dbs, sizeof(hb));
@@ -95,7 +93,7 @@ template <class Cv> static int32_t points_synthetic(dvn_ctx* ctx, uint64_t seed,
     if (!p) return fail(DVN_ERR_OOM, "host allocation failed");
     p->curve = curve; p->n = n;
     p->suite = SuiteOf<Cv>::value;
-    expand_plan(plan_curve<Cv>(curve), n, ScalarOf<Cv>::S::BITS, &p->expand_c, &p->nexp);
+    expand_plan(n, ScalarOf<Cv>::S::BITS, (size_t)Cv::AW * 4, &p->expand_c, &p->nexp);
     u32* dbs = nullptr;
     hipError_t e = hipMalloc((void**)&p->d, n ? n * Cv::AW * 4 * p->nexp : 16);
     if (e == hipSuccess) e = hipMalloc((void**)&dbs, sizeof(hb));
@@ -163,11 +161,9 @@ template <class Cv> static u32 pick_segment(size_t total) {
 // window sums for windows [win_lo, win_hi) -> host, internal packed xyzz images (XW words each)
 // ENQUEUE only: the kernels and the D2H copy of the window sums (into L.h_sums) are queued on the lane's stream;
 // lane_wait() completes them.
-// The sliced reduction of giant buckets (k_giant_*) runs only on curves whose field arithmetic is fully inlined.  On the
-// call-based instantiations (Fp2 curves, BW6-761: scratch-backed stack frames) the same kernels returned wrong sums and
-// memory faults on gfx950 while the G1 instantiation of the identical source checked out slice by slice; until that is
-// understood those curves keep the one-block-per-bucket path of k_fix_heavy.
-template <class Cv> struct GiantOk { static constexpr bool value = !Cv::O::CALL_MUL; };
+// sliced reduction of giant buckets (k_giant_*): on for every curve
+template <class Cv> struct GiantOk { static constexpr bool value = true; };
+static inline u32 fixh_grid() { static const u32 v = []() { const char* e = getenv("DVN_FIXH_GRID"); return e ? (u32)atoi(e) : 512u; }(); return v; }
 static inline u32 giant_threshold() {       // DVN_MSM_GIANT=<segments> overrides (debug / A-B); never below FIX_GIANT: giant_cap assumes it
     static const u32 v = []() { const char* e = getenv("DVN_MSM_GIANT"); const long x = e ? atol(e) : 0; return x > (long)FIX_GIANT ? (u32)x : FIX_GIANT; }();
     return v;
@@ -282,7 +278,7 @@ static int32_t msm_windows_staged(dvn_ctx* ctx, MsmLane& L, const dvn_points* pt
                                                                  heavy_count, 1, vb, seg, nseg, heavy_cap);
     DBG_SYNC("k_fix");
     const size_t sh_bytes = (size_t)256 * Cv::XW * 4;
-    k_fix_heavy<Cv><<<512, 256, sh_bytes, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list, heavy_count, vb, seg, nseg, heavy_cap,
+    k_fix_heavy<Cv><<<fixh_grid(), 256, sh_bytes, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list, heavy_count, vb, seg, nseg, heavy_cap,
                                                 giant_list, giant_count, giant_cap, GiantOk<Cv>::value ? giant_threshold() : 0xffffffffu);
     DBG_SYNC("k_fix_heavy");
     if constexpr (GiantOk<Cv>::value) {
@@ -387,7 +383,7 @@ static int32_t msm_windows(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, size
                                                                      heavy_count, W, nb, seg, nseg, heavy_cap);
     DBG_SYNC("k_fix");
     const size_t sh_bytes = (size_t)256 * Cv::XW * 4;
-    k_fix_heavy<Cv><<<512, 256, sh_bytes, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list, heavy_count, nb, seg, nseg, heavy_cap,
+    k_fix_heavy<Cv><<<fixh_grid(), 256, sh_bytes, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list, heavy_count, nb, seg, nseg, heavy_cap,
                                                 giant_list, giant_count, giant_cap, GiantOk<Cv>::value ? giant_threshold() : 0xffffffffu);
     DBG_SYNC("k_fix_heavy");
     if constexpr (GiantOk<Cv>::value) {
@@ -507,7 +503,7 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
                                                                  heavy_count, 1, nb, seg, nseg, heavy_cap);
     DBG_SYNC("k_fix");
     const size_t sh_bytes = (size_t)256 * Cv::XW * 4;
-    k_fix_heavy<Cv><<<512, 256, sh_bytes, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list, heavy_count, nb, seg, nseg, heavy_cap,
+    k_fix_heavy<Cv><<<fixh_grid(), 256, sh_bytes, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list, heavy_count, nb, seg, nseg, heavy_cap,
                                                 giant_list, giant_count, giant_cap, GiantOk<Cv>::value ? giant_threshold() : 0xffffffffu);
     DBG_SYNC("k_fix_heavy");
     if constexpr (GiantOk<Cv>::value) {

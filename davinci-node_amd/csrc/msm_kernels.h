@@ -605,8 +605,11 @@ __global__ __launch_bounds__(128) void k_fix(const u32* __restrict__ offsets, co
     st_xyzz<Cv>(acc, dst);
 }
 
-// block-cooperative sum of points in shared memory (blockDim.x power of two <= 256); result in lane 0
-template <class Cv> __device__ typename Cv::X block_sum(typename Cv::X v, u32* sh /* blockDim.x * XW words */) {
+// block-cooperative sum of points in shared memory (blockDim.x power of two <= 256); result in lane 0.
+// Always inlined: as a real function (which the compiler chose for the call-based Fp2 / BW6-761 instantiations) it reaches the
+// kernel's dynamic LDS through llvm.amdgcn.dynlds.offset.table indexed by an SGPR the caller does not keep alive across
+// calls -- the second call of a loop then addressed LDS out of range (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION on gfx950).
+template <class Cv> __device__ __forceinline__ typename Cv::X block_sum(typename Cv::X v, u32* sh /* blockDim.x * XW words */) {
     const u32 t = threadIdx.x;
     for (u32 stride = blockDim.x >> 1; stride >= 1; stride >>= 1) {
         if (t >= stride && t < 2 * stride) Cv::store_xyzz_internal(v, sh + (size_t)(t - stride) * Cv::XW);

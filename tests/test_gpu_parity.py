@@ -117,7 +117,10 @@ def test_msm_g1_linearity_and_window_sharding(ctx, orc, opy):
     pts = ctx.upload_g1(ph)
     a = orc.scalars(3, 0, n)
     want = orc.msm_g1(ph, a)
-    assert ctx.msm_plan_points(pts, n)[2] != 0                      # G1 sets are plain by default
+    assert ctx.msm_plan_points(pts, n) == (16, 16, 0)               # default policy: 2^15 <= n < 2^18 -> rows of 16-bit windows
+    assert (aff1(orc, ctx.msm_g1(pts, a)) == want).all()
+    pts.set_expanded(0)
+    assert ctx.msm_plan_points(pts, n)[2] != 0                      # plain set: per-window sums need the Horner combine
     pts.set_expanded(18)
     assert (pts.download(100, 50) == ph[100:150]).all()             # row 0 is untouched
     cw, nwin, cb = ctx.msm_plan_points(pts, n)
