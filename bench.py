@@ -35,6 +35,20 @@ MADS_PER_ADD = 1467            # v_mad_u64_u32 per XYZZ mixed addition in k_accu
 MAD_PEAK_PER_S = 35.4e12       # chip-wide v_mad_u64_u32 lane-op/s measured by tools/microbench (profiles/r01_instr_rate_microbench.txt)
 
 
+def pmc_traffic(log_n, world):
+    """HBM bytes per k_accumulate launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
+    separate runs of tools/prof_collect.sh, KiB -> bytes; raw counter values: the kernel reads 64-byte gathers, not the wide
+    streams the guide's x2 FETCH_SIZE correction was calibrated on).  Only valid for the workload it was collected on."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_msm_g1_2p22_v5_per_kernel.json")
+    if log_n != 22 or world != 1 or not os.path.exists(path):
+        return None, None
+    try:
+        k = [v for name, v in json.load(open(path)).items() if "k_accumulate" in name][0]
+        return round((k["FETCH_SIZE"]["max"] + k["WRITE_SIZE"]["max"]) * 1024 / 1e9, 3), "GB per launch, profiles/r01_pmc_msm_g1_2p22_v5_per_kernel.json"
+    except Exception:
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -222,6 +236,7 @@ def main():
         pairs_per_launch = n                         # k_accumulate consumes every (scalar, point) pair once per launch
         acc = float(np.mean(acc_ms))
         achieved = BYTES_PER_PAIR * pairs_per_launch / (acc * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(args.log_n, world)
         out = {
             "metric": "BN254 G1 MSM throughput @2^%d" % args.log_n, "value": round(value, 3), "unit": "Mscalar/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -231,7 +246,7 @@ def main():
                        "window_bits": c, "windows": nwin, "parallelism": "1 GPU, 2 MSMs in flight (two streams)" if world == 1 else f"window-sharded x{world}, RCCL all-gather, 2 steps in flight",
                        "inputs": "points + scalars resident in HBM", "result_checked": check},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_accumulate<G1>", "kernel_ms": round(acc, 4), "device_ms_per_step": round(float(np.mean(dev_ms)), 4),
                          "int_issue_context": {"note": "kernel is v_mad_u64_u32-issue bound, not HBM bound (DESIGN.md §4)",
                                                "mixed_additions_per_launch": n * (win_hi_all - win_lo_all),
