@@ -141,13 +141,17 @@ static void msm_plan(size_t n, u32* c_out, u32* nwin_out, u32 bits = 254) {
 // Segment length for k_accumulate: every lane executes exactly `seg` additions.  Measured (tools/gpu_seg.py, 2^22):
 // anything in 32..128 is within 3 %, longer segments lose to the tail of the last wave round, shorter ones to the
 // edge partials -- aim at >= 4 rounds of the resident lanes, clamp to [16, 128].
+// Kernel curve type: Fp2 curves run every group-arithmetic kernel of the MSM with one Fp2 component per lane (fp2_paired.h).
+// The memory images are identical, so host code and the point-set kernels keep the ordinary Curve<Fe2<C>>.
+template <class Cv> struct PairedOf { typedef Cv type; };
+template <class C> struct PairedOf<Curve<Fe2<C>>> { typedef Curve<Fe2P<C>> type; };
 template <class Cv> static u32 pick_segment(size_t total) {
-    static size_t slots = 0;                         // resident lanes of k_accumulate<Cv> on this device
+    static size_t slots = 0;                         // resident segments of the accumulate kernel on this device
     if (!slots) {
         int blocks = 0, dev = 0; hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, (const void*)k_accumulate<Cv>, 128, 0) == hipSuccess && blocks > 0)
-            slots = (size_t)prop.multiProcessorCount * blocks * 128;
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, (const void*)k_accumulate<typename PairedOf<Cv>::type>, 128, 0) == hipSuccess && blocks > 0)
+            slots = (size_t)prop.multiProcessorCount * blocks * 128 / Lanes<typename PairedOf<Cv>::type>::LPP;
         else { (void)hipGetLastError(); slots = 196608; }
     }
     static const int forced = []() { const char* v = getenv("DVN_MSM_SEG"); return v ? atoi(v) : 0; }();
@@ -163,7 +167,6 @@ template <class Cv> static u32 pick_segment(size_t total) {
 // lane_wait() completes them.
 // sliced reduction of giant buckets (k_giant_*): on for every curve
 template <class Cv> struct GiantOk { static constexpr bool value = true; };
-static inline u32 fixh_grid() { static const u32 v = []() { const char* e = getenv("DVN_FIXH_GRID"); return e ? (u32)atoi(e) : 512u; }(); return v; }
 static inline u32 giant_threshold() {       // DVN_MSM_GIANT=<segments> overrides (debug / A-B); never below FIX_GIANT: giant_cap assumes it
     static const u32 v = []() { const char* e = getenv("DVN_MSM_GIANT"); const long x = e ? atol(e) : 0; return x > (long)FIX_GIANT ? (u32)x : FIX_GIANT; }();
     return v;
@@ -186,6 +189,9 @@ static inline size_t s2_lds() { return ((size_t)4 * 1024 + 80 + ST) * 4 + (size_
 template <class Cv>
 static int32_t msm_windows_staged(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
                                   u32 c, u32 win_lo, u32 win_hi) {
+    typedef typename PairedOf<Cv>::type KC;
+    constexpr u32 LPP = Lanes<KC>::LPP;
+    static_assert(KC::XW == Cv::XW && KC::AW == Cv::AW, "paired and ordinary images must agree");
     const u32 W = win_hi - win_lo;
     const u32 nb = 1u << (c - 1);
     const u32 lob = c - 1 < 7 ? c - 1 : 7, lb = nb >> lob;             // <= 256 bins per window, 2^lob sub-buckets per bin
@@ -270,25 +276,25 @@ static int32_t msm_windows_staged(dvn_ctx* ctx, MsmLane& L, const dvn_points* pt
     k_s2_scatter<<<max_pieces, 1024, s2_lds(), st>>>(bin_base, piece_base, hbins, p1_ref, p1_lo, lob, counts, cursor, sorted, offsets);
     DBG_SYNC("k_s2_scatter");
     HIP_TRY(hipEventRecord(L.ev[2], st));
-    k_accumulate<Cv><<<(unsigned)(((size_t)nseg + 127) / 128), 128, 0, st>>>(pts->d, off, sorted, offsets, counts, totals, buckets,
+    k_accumulate<KC><<<(unsigned)(((size_t)nseg * LPP + 127) / 128), 128, 0, st>>>(pts->d, off, sorted, offsets, counts, totals, buckets,
                                                                           edge_first, edge_last, total, vb, seg, nseg, 1);
     DBG_SYNC("k_accumulate");
     HIP_TRY(hipEventRecord(L.ev[3], st));
-    k_fix<Cv><<<(unsigned)(((size_t)vb + 127) / 128), 128, 0, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list,
+    k_fix<KC><<<(unsigned)(((size_t)vb * LPP + 127) / 128), 128, 0, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list,
                                                                  heavy_count, 1, vb, seg, nseg, heavy_cap);
     DBG_SYNC("k_fix");
     const size_t sh_bytes = (size_t)256 * Cv::XW * 4;
-    k_fix_heavy<Cv><<<fixh_grid(), 256, sh_bytes, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list, heavy_count, vb, seg, nseg, heavy_cap,
+    k_fix_heavy<KC><<<512, 256 * LPP, sh_bytes, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list, heavy_count, vb, seg, nseg, heavy_cap,
                                                 giant_list, giant_count, giant_cap, GiantOk<Cv>::value ? giant_threshold() : 0xffffffffu);
     DBG_SYNC("k_fix_heavy");
     if constexpr (GiantOk<Cv>::value) {
-        k_giant_partial<Cv><<<1024, 256, sh_bytes, st>>>(offsets, counts, edge_first, edge_last, giant_list, giant_count, giant_cap, vb, seg, nseg, giant_part);
-        k_giant_final<Cv><<<64, GIANT_PIECES, (size_t)GIANT_PIECES * Cv::XW * 4, st>>>(giant_list, giant_count, giant_cap, giant_part, buckets);
+        k_giant_partial<KC><<<1024, 256 * LPP, sh_bytes, st>>>(offsets, counts, edge_first, edge_last, giant_list, giant_count, giant_cap, vb, seg, nseg, giant_part);
+        k_giant_final<KC><<<64, GIANT_PIECES * LPP, (size_t)GIANT_PIECES * Cv::XW * 4, st>>>(giant_list, giant_count, giant_cap, giant_part, buckets);
         DBG_SYNC("k_giant");
     }
-    k_bucket_reduce<Cv><<<W * bpw, 256, sh_bytes, st>>>(buckets, partials, nb, LB8, bpw);
+    k_bucket_reduce<KC><<<W * bpw, 256 * LPP, sh_bytes, st>>>(buckets, partials, nb, LB8, bpw);
     DBG_SYNC("k_bucket_reduce");
-    k_window_finalize<Cv><<<W, 64, (size_t)64 * Cv::XW * 4, st>>>(partials, wsums, W, bpw);
+    k_window_finalize<KC><<<W, 64 * LPP, (size_t)64 * Cv::XW * 4, st>>>(partials, wsums, W, bpw);
     DBG_SYNC("k_window_finalize");
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(L.ev[1], st));
@@ -300,106 +306,8 @@ static int32_t msm_windows_staged(dvn_ctx* ctx, MsmLane& L, const dvn_points* pt
 template <class Cv>
 static int32_t msm_windows(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
                            u32 c, u32 nwin, u32 win_lo, u32 win_hi) {
-    const u32 W = win_hi - win_lo;
-    {   // DVN_MSM_SORT=tile keeps the one-pass LDS-histogram tile sort (A/B switch)
-        static const bool tile_sort = []() { const char* v = getenv("DVN_MSM_SORT"); return v && !strcmp(v, "tile"); }();
-        if (!tile_sort) return msm_windows_staged<Cv>(ctx, L, pts, off, n, scalars, flags, c, win_lo, win_hi);
-    }
-    const u32 nb = 1u << (c - 1);
-    const u32 seg = pick_segment<Cv>((size_t)n * W);
-    const u32 nseg = (u32)((n + seg - 1) / seg);
-    const u32 LB8 = 8;                                             // buckets per thread in the reduction (latency-bound: keep chains short)
-    const u32 bpw = (nb + 256 * LB8 - 1) / (256 * LB8);                // reduction blocks per window
-    const u32 heavy_cap = (u32)(((size_t)W * nseg) / (FIX_LIGHT - 1) + 1);
-    const u32 giant_cap = heavy_cap / (FIX_GIANT / FIX_LIGHT) + 1;
-    const bool on_dev = flags & DVN_MSM_SCALARS_ON_DEVICE;
-
-    const u32 tile_len = 65536;
-    const u32 ntiles = (u32)((n + tile_len - 1) / tile_len);
-    CarverSize cs;
-    constexpr size_t SB = ScalarOf<Cv>::S::EW * 4;       // bytes per scalar
-    if (!on_dev) cs.take(n * SB);
-    cs.take((size_t)W * n * 2); cs.take((size_t)W * n * 4);          // digits (int16), sorted
-    cs.take((size_t)W * ntiles * nb * 4);                             // per-tile histograms
-    cs.take((size_t)W * nb * 4 * 2); cs.take((size_t)W * 4 + 8);      // counts, offsets; totals + heavy_count + giant_count
-    cs.take((size_t)heavy_cap * 4);
-    cs.take((size_t)giant_cap * 4); cs.take((size_t)giant_cap * GIANT_PIECES * Cv::XW * 4);
-    cs.take((size_t)W * nb * Cv::XW * 4);                             // bucket sums
-    cs.take((size_t)W * nseg * Cv::XW * 4); cs.take((size_t)W * nseg * Cv::XW * 4);   // edges
-    cs.take((size_t)W * bpw * Cv::XW * 4); cs.take((size_t)W * Cv::XW * 4);
-    TRY(lane_ensure_ws(L, cs.off + 8192));
-    Carver cv(L.ws);
-    const u32* d_scalars;
-    if (!on_dev) {
-        u32* tmp = cv.take<u32>(n * (SB / 4));
-        HIP_TRY(hipMemcpy(tmp, scalars, n * SB, hipMemcpyHostToDevice));   // caller's buffer is free on return (cgo rule)
-        d_scalars = tmp;
-    } else d_scalars = (const u32*)scalars;
-    int16_t* digits = cv.take<int16_t>((size_t)W * n);
-    u32* sorted = cv.take<u32>((size_t)W * n);
-    u32* hist = cv.take<u32>((size_t)W * ntiles * nb);
-    u32* counts = cv.take<u32>((size_t)W * nb * 2);
-    u32* offsets = counts + (size_t)W * nb;
-    u32* totals = cv.take<u32>(W + 2);
-    u32* heavy_count = totals + W;
-    u32* giant_count = totals + W + 1;
-    u32* heavy_list = cv.take<u32>(heavy_cap);
-    u32* giant_list = cv.take<u32>(giant_cap);
-    u32* giant_part = cv.take<u32>((size_t)giant_cap * GIANT_PIECES * Cv::XW);
-    u32* buckets = cv.take<u32>((size_t)W * nb * Cv::XW);
-    u32* edge_first = cv.take<u32>((size_t)W * nseg * Cv::XW);
-    u32* edge_last = cv.take<u32>((size_t)W * nseg * Cv::XW);
-    u32* partials = cv.take<u32>((size_t)W * bpw * Cv::XW);
-    u32* wsums = cv.take<u32>((size_t)W * Cv::XW);
-
-    hipStream_t st = L.stream;
-    static const bool dbg = getenv("DVN_DEBUG_SYNC") != nullptr;
-    if (dbg) { fprintf(stderr, "[dvn] msm n=%zu c=%u W=%u nb=%u seg=%u nseg=%u bpw=%u ntiles=%u ws=%zu\n", n, c, W, nb, seg, nseg, bpw, ntiles, cs.off); fflush(stderr); }
-    const size_t hist_lds = (size_t)nb * 4;
-    static bool lds_attr_set = false;
-    if (!lds_attr_set) {   // 2^15 counters = 128 KiB of the CU's 160 KiB LDS: above the 64 KiB default cap
-        HIP_TRY(hipFuncSetAttribute((const void*)k_tile_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_tile_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        lds_attr_set = true;
-    }
-    HIP_TRY(hipEventRecord(L.ev[0], st));
-    HIP_TRY(hipMemsetAsync(totals, 0, (size_t)(W + 2) * 4, st));
-    k_digits16<typename ScalarOf<Cv>::S><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_scalars, n, c, win_lo, win_hi, digits);
-    DBG_SYNC("k_digits16");
-    k_tile_hist<<<W * ntiles, 1024, hist_lds, st>>>(digits, n, nb, tile_len, ntiles, hist);
-    DBG_SYNC("k_tile_hist");
-    k_tile_offsets<<<(unsigned)(((size_t)W * nb + 255) / 256), 256, 0, st>>>(hist, counts, nb, ntiles, W);
-    DBG_SYNC("k_tile_offsets");
-    k_scan<<<W, 1024, 0, st>>>(counts, offsets, totals, nb);
-    DBG_SYNC("k_scan");
-    k_tile_scatter<<<W * ntiles, 1024, hist_lds, st>>>(digits, n, nb, tile_len, ntiles, hist, offsets, sorted);
-    DBG_SYNC("k_tile_scatter");
-    HIP_TRY(hipEventRecord(L.ev[2], st));
-    k_accumulate<Cv><<<(unsigned)(((size_t)W * nseg + 127) / 128), 128, 0, st>>>(pts->d, off, sorted, offsets, counts, totals, buckets,
-                                                                              edge_first, edge_last, n, nb, seg, nseg, W);
-    DBG_SYNC("k_accumulate");
-    HIP_TRY(hipEventRecord(L.ev[3], st));
-    k_fix<Cv><<<(unsigned)(((size_t)W * nb + 127) / 128), 128, 0, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list,
-                                                                     heavy_count, W, nb, seg, nseg, heavy_cap);
-    DBG_SYNC("k_fix");
-    const size_t sh_bytes = (size_t)256 * Cv::XW * 4;
-    k_fix_heavy<Cv><<<fixh_grid(), 256, sh_bytes, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list, heavy_count, nb, seg, nseg, heavy_cap,
-                                                giant_list, giant_count, giant_cap, GiantOk<Cv>::value ? giant_threshold() : 0xffffffffu);
-    DBG_SYNC("k_fix_heavy");
-    if constexpr (GiantOk<Cv>::value) {
-        k_giant_partial<Cv><<<1024, 256, sh_bytes, st>>>(offsets, counts, edge_first, edge_last, giant_list, giant_count, giant_cap, nb, seg, nseg, giant_part);
-        k_giant_final<Cv><<<64, GIANT_PIECES, (size_t)GIANT_PIECES * Cv::XW * 4, st>>>(giant_list, giant_count, giant_cap, giant_part, buckets);
-        DBG_SYNC("k_giant");
-    }
-    k_bucket_reduce<Cv><<<W * bpw, 256, sh_bytes, st>>>(buckets, partials, nb, LB8, bpw);
-    DBG_SYNC("k_bucket_reduce");
-    k_window_finalize<Cv><<<W, 64, (size_t)64 * Cv::XW * 4, st>>>(partials, wsums, W, bpw);
-    DBG_SYNC("k_window_finalize");
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(L.ev[1], st));
-    if ((size_t)W * Cv::XW > DVN_HSUMS_WORDS) return fail(DVN_ERR_INVALID_ARG, "too many windows for the result buffer");
-    HIP_TRY(hipMemcpyAsync(L.h_sums, wsums, (size_t)W * Cv::XW * 4, hipMemcpyDeviceToHost, st));
-    return DVN_OK;
+    (void)nwin;
+    return msm_windows_staged<Cv>(ctx, L, pts, off, n, scalars, flags, c, win_lo, win_hi);
 }
 
 // --------------------------------------------------------------------------------------------------------------------
@@ -413,6 +321,8 @@ static inline bool use_expanded(const dvn_points* pts, size_t n) {
 template <class Cv>
 static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
                             u32 win_lo, u32 win_hi) {
+    typedef typename PairedOf<Cv>::type KC;
+    constexpr u32 LPP = Lanes<KC>::LPP;
     const u32 c = pts->expand_c, W = win_hi - win_lo;
     const u32 nb = 1u << (c - 1);
     const u32 lob = (c - 1 + 1) / 2 < 10 ? (c - 1 + 1) / 2 : 10, lb = nb >> lob;        // balanced split of the bucket bits
@@ -495,25 +405,25 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
     k_s2_scatter<<<max_pieces, 1024, s2_lds(), st>>>(bin_base, piece_base, lb, p1_ref, p1_lo, lob, counts, cursor, sorted, offsets);
     DBG_SYNC("k_s2_scatter");
     HIP_TRY(hipEventRecord(L.ev[2], st));
-    k_accumulate<Cv><<<(unsigned)(((size_t)nseg + 127) / 128), 128, 0, st>>>(pts->d, 0, sorted, offsets, counts, totals, buckets,
+    k_accumulate<KC><<<(unsigned)(((size_t)nseg * LPP + 127) / 128), 128, 0, st>>>(pts->d, 0, sorted, offsets, counts, totals, buckets,
                                                                           edge_first, edge_last, total, nb, seg, nseg, 1);
     DBG_SYNC("k_accumulate");
     HIP_TRY(hipEventRecord(L.ev[3], st));
-    k_fix<Cv><<<(unsigned)(((size_t)nb + 127) / 128), 128, 0, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list,
+    k_fix<KC><<<(unsigned)(((size_t)nb * LPP + 127) / 128), 128, 0, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list,
                                                                  heavy_count, 1, nb, seg, nseg, heavy_cap);
     DBG_SYNC("k_fix");
     const size_t sh_bytes = (size_t)256 * Cv::XW * 4;
-    k_fix_heavy<Cv><<<fixh_grid(), 256, sh_bytes, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list, heavy_count, nb, seg, nseg, heavy_cap,
+    k_fix_heavy<KC><<<512, 256 * LPP, sh_bytes, st>>>(offsets, counts, buckets, edge_first, edge_last, heavy_list, heavy_count, nb, seg, nseg, heavy_cap,
                                                 giant_list, giant_count, giant_cap, GiantOk<Cv>::value ? giant_threshold() : 0xffffffffu);
     DBG_SYNC("k_fix_heavy");
     if constexpr (GiantOk<Cv>::value) {
-        k_giant_partial<Cv><<<1024, 256, sh_bytes, st>>>(offsets, counts, edge_first, edge_last, giant_list, giant_count, giant_cap, nb, seg, nseg, giant_part);
-        k_giant_final<Cv><<<64, GIANT_PIECES, (size_t)GIANT_PIECES * Cv::XW * 4, st>>>(giant_list, giant_count, giant_cap, giant_part, buckets);
+        k_giant_partial<KC><<<1024, 256 * LPP, sh_bytes, st>>>(offsets, counts, edge_first, edge_last, giant_list, giant_count, giant_cap, nb, seg, nseg, giant_part);
+        k_giant_final<KC><<<64, GIANT_PIECES * LPP, (size_t)GIANT_PIECES * Cv::XW * 4, st>>>(giant_list, giant_count, giant_cap, giant_part, buckets);
         DBG_SYNC("k_giant");
     }
-    k_bucket_reduce<Cv><<<bpw, 256, sh_bytes, st>>>(buckets, partials, nb, LB8, bpw);
+    k_bucket_reduce<KC><<<bpw, 256 * LPP, sh_bytes, st>>>(buckets, partials, nb, LB8, bpw);
     DBG_SYNC("k_bucket_reduce");
-    k_window_finalize<Cv><<<1, 64, (size_t)64 * Cv::XW * 4, st>>>(partials, wsum, 1, bpw);
+    k_window_finalize<KC><<<1, 64 * LPP, (size_t)64 * Cv::XW * 4, st>>>(partials, wsum, 1, bpw);
     DBG_SYNC("k_window_finalize");
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(L.ev[1], st));

@@ -4,19 +4,20 @@
 // five times per proof (/root/reference/prover/prover_cpu.go:37 -> gnark backend/groth16/bn254/prove.go).
 //
 // Pipeline (DESIGN.md "MSM"):
-//   k_digits16    scalar (Montgomery) -> canonical -> signed c-bit digits (int16) for every window
-//   k_tile_hist / k_tile_offsets / k_scan / k_tile_scatter
-//                 per-window counting sort of (point index | sign) by bucket: 64K-entry tiles, the whole 2^(c-1)-
-//                 counter histogram of a tile lives in LDS (128 KiB at c = 16), every rank comes from an LDS atomic
+//   k_digits16/32 scalar (Montgomery) -> canonical -> signed c-bit digits for every window
+//   k_s1_* / k_s2_*   two-pass LDS-staged counting sort of (point ref | sign) by (window, bucket): both passes rank
+//                 with LDS atomics, reorder their 8192-entry tile in LDS and write runs
 //   k_accumulate  HOT KERNEL: one lane per fixed-size SEGMENT of the sorted list (not per bucket), so every
 //                 lane of a wave does exactly SEG mixed additions whatever the scalar distribution is; runs
 //                 that a segment shares with its neighbours are written as edge partials
-//   k_fix / k_fix_heavy   stitch the edge partials of buckets that span segments (heavy = block-cooperative)
+//   k_fix / k_fix_heavy / k_giant_*   stitch the edge partials of buckets that span segments (heavy = block-
+//                 cooperative, giant = 64 blocks per bucket)
 //   k_bucket_reduce + k_window_finalize   sum_b b * B_b per window: chunked running sums + small scalar mul +
 //                 LDS tree
 //   host          Horner combine of the <= 32 window sums (O(254) group operations)
 #pragma once
 #include "bn254_curve.h"
+#include "fp2_paired.h"
 
 namespace dvn {
 
@@ -33,29 +34,46 @@ __device__ __forceinline__ void store_words16(u32* __restrict__ p, const u32* w,
     for (int i = 0; i < nwords; i += 4) *reinterpret_cast<uint4*>(p + i) = make_uint4(w[i], w[i + 1], w[i + 2], w[i + 3]);
 }
 
+// Lane layout of a kernel's curve type: 1 lane per point, or 2 for the paired Fp2 arithmetic (fp2_paired.h: one Fp2
+// component per lane).  Kernels index their work by LOGICAL thread: ltid / lbdim / lgtid.
+template <class Cv> struct Lanes { static constexpr u32 LPP = 1; };
+template <class C> struct Lanes<Curve<Fe2P<C>>> { static constexpr u32 LPP = 2; };
+template <class Cv> __device__ __forceinline__ u32 ltid() { return threadIdx.x / Lanes<Cv>::LPP; }
+template <class Cv> __device__ __forceinline__ u32 lbdim() { return blockDim.x / Lanes<Cv>::LPP; }
+template <class Cv> __device__ __forceinline__ size_t lgtid() { return ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / Lanes<Cv>::LPP; }
+
 template <class Cv> __device__ __forceinline__ typename Cv::A ld_affine(const u32* __restrict__ p) {
-    u32 w[Cv::AW];
+    if constexpr (Lanes<Cv>::LPP == 2) return ld_affine_paired<Cv>(p);
+    else {
+        u32 w[Cv::AW];
 #pragma unroll
-    for (int i = 0; i < Cv::AW; i += 4) {
-        uint4 v = *reinterpret_cast<const uint4*>(p + i);
-        w[i] = v.x; w[i + 1] = v.y; w[i + 2] = v.z; w[i + 3] = v.w;
+        for (int i = 0; i < Cv::AW; i += 4) {
+            uint4 v = *reinterpret_cast<const uint4*>(p + i);
+            w[i] = v.x; w[i + 1] = v.y; w[i + 2] = v.z; w[i + 3] = v.w;
+        }
+        return Cv::load_affine_internal(w);
     }
-    return Cv::load_affine_internal(w);
 }
 template <class Cv> __device__ __forceinline__ typename Cv::X ld_xyzz(const u32* __restrict__ p) {
-    u32 w[Cv::XW];
+    if constexpr (Lanes<Cv>::LPP == 2) return ld_xyzz_paired<Cv>(p);
+    else {
+        u32 w[Cv::XW];
 #pragma unroll
-    for (int i = 0; i < Cv::XW; i += 4) {
-        uint4 v = *reinterpret_cast<const uint4*>(p + i);
-        w[i] = v.x; w[i + 1] = v.y; w[i + 2] = v.z; w[i + 3] = v.w;
+        for (int i = 0; i < Cv::XW; i += 4) {
+            uint4 v = *reinterpret_cast<const uint4*>(p + i);
+            w[i] = v.x; w[i + 1] = v.y; w[i + 2] = v.z; w[i + 3] = v.w;
+        }
+        return Cv::load_xyzz_internal(w);
     }
-    return Cv::load_xyzz_internal(w);
 }
 template <class Cv> __device__ __forceinline__ void st_xyzz(const typename Cv::X& pt, u32* __restrict__ p) {
-    u32 w[Cv::XW];
-    Cv::store_xyzz_internal(pt, w);
+    if constexpr (Lanes<Cv>::LPP == 2) st_xyzz_paired<Cv>(pt, p);
+    else {
+        u32 w[Cv::XW];
+        Cv::store_xyzz_internal(pt, w);
 #pragma unroll
-    for (int i = 0; i < Cv::XW; i += 4) *reinterpret_cast<uint4*>(p + i) = make_uint4(w[i], w[i + 1], w[i + 2], w[i + 3]);
+        for (int i = 0; i < Cv::XW; i += 4) *reinterpret_cast<uint4*>(p + i) = make_uint4(w[i], w[i + 1], w[i + 2], w[i + 3]);
+    }
 }
 
 // ---- points: external gnark image -> internal image, in place ------------------------------------------
@@ -171,77 +189,6 @@ template <class S> __global__ void k_digits16(const u32* __restrict__ scalars, s
         if (d >= nb) { v = (int)d - (int)(1u << c); carry = 1; }
         if (win >= win_lo) digits[(size_t)(win - win_lo) * n + i] = (int16_t)v;
     }
-}
-
-// block (w, tile): histogram of the tile's bucket indices in LDS -> hist[(w * ntiles + tile) * nb + b]
-static __global__ __launch_bounds__(1024) void k_tile_hist(const int16_t* __restrict__ digits, size_t n, u32 nb, u32 tile_len,
-                                                           u32 ntiles, u32* __restrict__ hist) {
-    extern __shared__ __align__(16) u32 lh[];
-    const u32 w = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
-    for (u32 b = threadIdx.x; b < nb; b += blockDim.x) lh[b] = 0;
-    __syncthreads();
-    const size_t lo = (size_t)tile * tile_len, hi = min(lo + (size_t)tile_len, n);
-    const int16_t* dg = digits + (size_t)w * n;
-    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const int d = dg[i];
-        if (d) atomicAdd(&lh[(d < 0 ? -d : d) - 1], 1u);
-    }
-    __syncthreads();
-    u32* out = hist + (size_t)blockIdx.x * nb;
-    for (u32 b = threadIdx.x; b < nb; b += blockDim.x) out[b] = lh[b];
-}
-// thread (w, b): exclusive prefix of hist over the tiles of window w, in place; counts[w][b] = total
-static __global__ void k_tile_offsets(u32* __restrict__ hist, u32* __restrict__ counts, u32 nb, u32 ntiles, u32 nwin_local) {
-    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= (size_t)nwin_local * nb) return;
-    const u32 w = (u32)(g / nb), b = (u32)(g % nb);
-    u32 run = 0;
-    u32* p = hist + (size_t)w * ntiles * nb + b;
-    for (u32 t = 0; t < ntiles; ++t, p += nb) { const u32 v = *p; *p = run; run += v; }
-    counts[g] = run;
-}
-// block (w, tile): final position of every entry = offsets[w][b] + hist[w][tile][b] + rank inside the tile
-static __global__ __launch_bounds__(1024) void k_tile_scatter(const int16_t* __restrict__ digits, size_t n, u32 nb, u32 tile_len,
-                                                              u32 ntiles, const u32* __restrict__ hist,
-                                                              const u32* __restrict__ offsets, u32* __restrict__ sorted) {
-    extern __shared__ __align__(16) u32 lh[];
-    const u32 w = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
-    const u32* hb = hist + (size_t)blockIdx.x * nb;
-    const u32* ob = offsets + (size_t)w * nb;
-    for (u32 b = threadIdx.x; b < nb; b += blockDim.x) lh[b] = hb[b] + ob[b];
-    __syncthreads();
-    const size_t lo = (size_t)tile * tile_len, hi = min(lo + (size_t)tile_len, n);
-    const int16_t* dg = digits + (size_t)w * n;
-    u32* dst = sorted + (size_t)w * n;
-    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const int d = dg[i];
-        if (d) {
-            const u32 pos = atomicAdd(&lh[(d < 0 ? -d : d) - 1], 1u);
-            dst[pos] = (u32)i | (d < 0 ? SIGN_BIT : 0u);
-        }
-    }
-}
-
-// one block per window: offsets = exclusive scan of counts; totals[w] = number of entries
-static __global__ void k_scan(const u32* __restrict__ counts, u32* __restrict__ offsets, u32* __restrict__ totals, u32 nb) {
-    __shared__ u32 part[1024];
-    const u32 w = blockIdx.x, t = threadIdx.x, T = blockDim.x;
-    const u32 per = (nb + T - 1) / T;
-    const u32 lo = t * per, hi = min(lo + per, nb);
-    const u32* cw = counts + (size_t)w * nb;
-    u32 s = 0;
-    for (u32 b = lo; b < hi; ++b) s += cw[b];
-    part[t] = s;
-    __syncthreads();
-    for (u32 d = 1; d < T; d <<= 1) {
-        u32 v = (t >= d) ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    u32 run = part[t] - s;
-    for (u32 b = lo; b < hi; ++b) { offsets[(size_t)w * nb + b] = run; run += cw[b]; }
-    if (t == T - 1) totals[w] = part[t];
 }
 
 // ====================================================================================================================
@@ -531,7 +478,7 @@ __global__ __launch_bounds__(128) void k_accumulate(const u32* __restrict__ poin
                                                     u32 nwin_local) {
     typedef typename Cv::X X;
     typedef typename Cv::A A;
-    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t g = lgtid<Cv>();
     const u32 w = (u32)(g / nseg);
     if (w >= nwin_local) return;
     const u32 k = (u32)(g - (size_t)w * nseg);
@@ -584,7 +531,7 @@ __global__ __launch_bounds__(128) void k_fix(const u32* __restrict__ offsets, co
                                              u32* __restrict__ heavy_count, u32 nwin_local, u32 nb, u32 seg, u32 nseg,
                                              u32 heavy_cap) {
     typedef typename Cv::X X;
-    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t g = lgtid<Cv>();
     if (g >= (size_t)nwin_local * nb) return;
     const u32 w = (u32)(g / nb);
     const u32 c = counts[g];
@@ -594,8 +541,10 @@ __global__ __launch_bounds__(128) void k_fix(const u32* __restrict__ offsets, co
     const u32 ks = o / seg, ke = (e - 1) / seg;
     if (ks == ke) return;                       // complete inside one segment: written by k_accumulate
     if (ke - ks + 1 > FIX_LIGHT) {
-        const u32 slot = atomicAdd(heavy_count, 1u);
-        if (slot < heavy_cap) heavy_list[slot] = (u32)g;
+        if (threadIdx.x % Lanes<Cv>::LPP == 0) {
+            const u32 slot = atomicAdd(heavy_count, 1u);
+            if (slot < heavy_cap) heavy_list[slot] = (u32)g;
+        }
         return;
     }
     const u32* first = edge_first + (size_t)w * nseg * Cv::XW;
@@ -610,18 +559,18 @@ __global__ __launch_bounds__(128) void k_fix(const u32* __restrict__ offsets, co
 // kernel's dynamic LDS through llvm.amdgcn.dynlds.offset.table indexed by an SGPR the caller does not keep alive across
 // calls -- the second call of a loop then addressed LDS out of range (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION on gfx950).
 template <class Cv> __device__ __forceinline__ typename Cv::X block_sum(typename Cv::X v, u32* sh /* blockDim.x * XW words */) {
-    const u32 t = threadIdx.x;
-    for (u32 stride = blockDim.x >> 1; stride >= 1; stride >>= 1) {
-        if (t >= stride && t < 2 * stride) Cv::store_xyzz_internal(v, sh + (size_t)(t - stride) * Cv::XW);
+    const u32 t = ltid<Cv>();
+    for (u32 stride = lbdim<Cv>() >> 1; stride >= 1; stride >>= 1) {
+        if (t >= stride && t < 2 * stride) st_xyzz<Cv>(v, sh + (size_t)(t - stride) * Cv::XW);
         __syncthreads();
-        if (t < stride) v = Cv::add(v, Cv::load_xyzz_internal(sh + (size_t)t * Cv::XW));
+        if (t < stride) v = Cv::add(v, ld_xyzz<Cv>(sh + (size_t)t * Cv::XW));
         __syncthreads();
     }
     return v;
 }
 
 template <class Cv>
-__global__ __launch_bounds__(256) void k_fix_heavy(const u32* __restrict__ offsets, const u32* __restrict__ counts,
+__global__ __launch_bounds__(256 * Lanes<Cv>::LPP) void k_fix_heavy(const u32* __restrict__ offsets, const u32* __restrict__ counts,
                                                    u32* __restrict__ bucket_sums, const u32* __restrict__ edge_first,
                                                    const u32* __restrict__ edge_last, const u32* __restrict__ heavy_list,
                                                    const u32* __restrict__ heavy_count, u32 nb, u32 seg, u32 nseg, u32 heavy_cap,
@@ -641,12 +590,12 @@ __global__ __launch_bounds__(256) void k_fix_heavy(const u32* __restrict__ offse
         const u32* first = edge_first + (size_t)w * nseg * Cv::XW;
         const u32* last = edge_last + (size_t)w * nseg * Cv::XW;
         X acc = Cv::infinity();
-        for (u32 k = ks + threadIdx.x; k <= ke; k += blockDim.x) {
+        for (u32 k = ks + ltid<Cv>(); k <= ke; k += lbdim<Cv>()) {
             const u32* src = (k == ks && (o % seg) != 0) ? last : first;
             acc = Cv::add(acc, ld_xyzz<Cv>(src + (size_t)k * Cv::XW));
         }
         acc = block_sum<Cv>(acc, sh);
-        if (threadIdx.x == 0) st_xyzz<Cv>(acc, bucket_sums + (size_t)g * Cv::XW);
+        if (ltid<Cv>() == 0) st_xyzz<Cv>(acc, bucket_sums + (size_t)g * Cv::XW);
         __syncthreads();
     }
 }
@@ -655,7 +604,7 @@ __global__ __launch_bounds__(256) void k_fix_heavy(const u32* __restrict__ offse
 // into 18- or 21-bit windows, puts a quarter of ALL entries into one bucket): GIANT_PIECES blocks per bucket sum slices of
 // its segment partials, a second small kernel adds the slices up.
 template <class Cv>
-__global__ __launch_bounds__(256) void k_giant_partial(const u32* __restrict__ offsets, const u32* __restrict__ counts,
+__global__ __launch_bounds__(256 * Lanes<Cv>::LPP) void k_giant_partial(const u32* __restrict__ offsets, const u32* __restrict__ counts,
                                                        const u32* __restrict__ edge_first, const u32* __restrict__ edge_last,
                                                        const u32* __restrict__ giant_list, const u32* __restrict__ giant_count, u32 giant_cap,
                                                        u32 nb, u32 seg, u32 nseg, u32* __restrict__ giant_part) {
@@ -672,24 +621,24 @@ __global__ __launch_bounds__(256) void k_giant_partial(const u32* __restrict__ o
         const u32* first = edge_first + (size_t)w * nseg * Cv::XW;
         const u32* last = edge_last + (size_t)w * nseg * Cv::XW;
         X acc = Cv::infinity();
-        for (u32 k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
+        for (u32 k = k0 + ltid<Cv>(); k < k1; k += lbdim<Cv>()) {
             const u32* src = (k == ks && (o % seg) != 0) ? last : first;
             acc = Cv::add(acc, ld_xyzz<Cv>(src + (size_t)k * Cv::XW));
         }
         acc = block_sum<Cv>(acc, sh);
-        if (threadIdx.x == 0) st_xyzz<Cv>(acc, giant_part + (size_t)it * Cv::XW);
+        if (ltid<Cv>() == 0) st_xyzz<Cv>(acc, giant_part + (size_t)it * Cv::XW);
         __syncthreads();
     }
 }
 template <class Cv>
-__global__ __launch_bounds__(64) void k_giant_final(const u32* __restrict__ giant_list, const u32* __restrict__ giant_count, u32 giant_cap,
+__global__ __launch_bounds__(64 * Lanes<Cv>::LPP) void k_giant_final(const u32* __restrict__ giant_list, const u32* __restrict__ giant_count, u32 giant_cap,
                                                     const u32* __restrict__ giant_part, u32* __restrict__ bucket_sums) {
     extern __shared__ __align__(16) u32 sh[];
     const u32 ng = min(*giant_count, giant_cap);
-    for (u32 h = blockIdx.x; h < ng; h += gridDim.x) {             // blockDim.x == GIANT_PIECES
-        typename Cv::X acc = ld_xyzz<Cv>(giant_part + ((size_t)h * GIANT_PIECES + threadIdx.x) * Cv::XW);
+    for (u32 h = blockIdx.x; h < ng; h += gridDim.x) {             // logical block size == GIANT_PIECES
+        typename Cv::X acc = ld_xyzz<Cv>(giant_part + ((size_t)h * GIANT_PIECES + ltid<Cv>()) * Cv::XW);
         acc = block_sum<Cv>(acc, sh);
-        if (threadIdx.x == 0) st_xyzz<Cv>(acc, bucket_sums + (size_t)giant_list[h] * Cv::XW);
+        if (ltid<Cv>() == 0) st_xyzz<Cv>(acc, bucket_sums + (size_t)giant_list[h] * Cv::XW);
         __syncthreads();
     }
 }
@@ -697,12 +646,12 @@ __global__ __launch_bounds__(64) void k_giant_final(const u32* __restrict__ gian
 // ---- bucket reduction: window sum = sum_{b=1..nb} b * B_b -------------------------------------------------
 // block handles blockDim.x * L consecutive buckets of one window; thread handles L of them.
 template <class Cv>
-__global__ __launch_bounds__(256) void k_bucket_reduce(const u32* __restrict__ bucket_sums, u32* __restrict__ partials,
+__global__ __launch_bounds__(256 * Lanes<Cv>::LPP) void k_bucket_reduce(const u32* __restrict__ bucket_sums, u32* __restrict__ partials,
                                                        u32 nb, u32 L, u32 blocks_per_window) {
     typedef typename Cv::X X;
     extern __shared__ __align__(16) u32 sh[];
     const u32 w = blockIdx.x / blocks_per_window, blk = blockIdx.x % blocks_per_window;
-    const u32 first = (blk * blockDim.x + threadIdx.x) * L;     // 0-based index of this thread's first bucket
+    const u32 first = (blk * lbdim<Cv>() + ltid<Cv>()) * L;     // 0-based index of this thread's first bucket
     X run = Cv::infinity(), tot = Cv::infinity();
     if (first < nb) {
         const u32 last = min(first + L, nb);
@@ -715,20 +664,20 @@ __global__ __launch_bounds__(256) void k_bucket_reduce(const u32* __restrict__ b
         if (first) tot = Cv::add(tot, Cv::mul_small(run, first));
     }
     tot = block_sum<Cv>(tot, sh);
-    if (threadIdx.x == 0) st_xyzz<Cv>(tot, partials + (size_t)blockIdx.x * Cv::XW);
+    if (ltid<Cv>() == 0) st_xyzz<Cv>(tot, partials + (size_t)blockIdx.x * Cv::XW);
 }
 // one small block per window: tree-sum of the window's partial results
 template <class Cv>
-__global__ __launch_bounds__(64) void k_window_finalize(const u32* __restrict__ partials, u32* __restrict__ window_sums, u32 nwin_local,
+__global__ __launch_bounds__(64 * Lanes<Cv>::LPP) void k_window_finalize(const u32* __restrict__ partials, u32* __restrict__ window_sums, u32 nwin_local,
                                                         u32 blocks_per_window) {
     typedef typename Cv::X X;
     extern __shared__ __align__(16) u32 sh[];
     const u32 w = blockIdx.x;
     X acc = Cv::infinity();
-    for (u32 i = threadIdx.x; i < blocks_per_window; i += blockDim.x)
+    for (u32 i = ltid<Cv>(); i < blocks_per_window; i += lbdim<Cv>())
         acc = Cv::add(acc, ld_xyzz<Cv>(partials + ((size_t)w * blocks_per_window + i) * Cv::XW));
     acc = block_sum<Cv>(acc, sh);
-    if (threadIdx.x == 0) st_xyzz<Cv>(acc, window_sums + (size_t)w * Cv::XW);
+    if (ltid<Cv>() == 0) st_xyzz<Cv>(acc, window_sums + (size_t)w * Cv::XW);
     (void)nwin_local;
 }
 
