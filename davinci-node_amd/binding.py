@@ -99,6 +99,7 @@ def load_library():
         "dvn_bls12377_msm_g2": (i32, [vp, vp, sz, sz, vp, u32, vp]),
         "dvn_bls12377_ntt_domain": (i32, [vp, u32, C.POINTER(vp)]),
         "dvn_bls12377_ntt": (i32, [vp, vp, vp, C.c_int, C.c_int, C.c_int, u32]),
+        "dvn_bls12377_groth16_compute_h": (i32, [vp, vp, vp, vp, vp, sz, vp, u32]),
         "dvn_bls12381_points_upload_g1": (i32, [vp, vp, sz, C.POINTER(vp)]),
         "dvn_bls12381_points_upload_g2": (i32, [vp, vp, sz, C.POINTER(vp)]),
         "dvn_bls12381_points_synthetic_g1": (i32, [vp, u64, sz, C.POINTER(vp)]),
@@ -108,6 +109,7 @@ def load_library():
         "dvn_bls12381_msm_g2": (i32, [vp, vp, sz, sz, vp, u32, vp]),
         "dvn_bls12381_ntt_domain": (i32, [vp, u32, C.POINTER(vp)]),
         "dvn_bls12381_ntt": (i32, [vp, vp, vp, C.c_int, C.c_int, C.c_int, u32]),
+        "dvn_bls12381_groth16_compute_h": (i32, [vp, vp, vp, vp, vp, sz, vp, u32]),
         "dvn_bw6761_points_upload": (i32, [vp, C.c_int, vp, sz, C.POINTER(vp)]),
         "dvn_bw6761_points_synthetic": (i32, [vp, C.c_int, vp, u64, sz, C.POINTER(vp)]),
         "dvn_bw6761_points_download": (i32, [vp, vp, sz, sz, vp]),
@@ -139,9 +141,9 @@ EXPORTED_SYMBOLS = [
     "dvn_groth16_setup", "dvn_groth16_pk_info", "dvn_groth16_pk_free", "dvn_groth16_prove", "dvn_groth16_last_ms",
     "dvn_groth16_proof_abi_encode", "dvn_pedersen_commit",
     "dvn_bls12377_points_upload_g1", "dvn_bls12377_points_upload_g2", "dvn_bls12377_points_synthetic_g1", "dvn_bls12377_points_download",
-    "dvn_bls12377_scalars_synthetic", "dvn_bls12377_msm_g1", "dvn_bls12377_msm_g2", "dvn_bls12377_ntt_domain", "dvn_bls12377_ntt",
+    "dvn_bls12377_scalars_synthetic", "dvn_bls12377_msm_g1", "dvn_bls12377_msm_g2", "dvn_bls12377_ntt_domain", "dvn_bls12377_ntt", "dvn_bls12377_groth16_compute_h",
     "dvn_bls12381_points_upload_g1", "dvn_bls12381_points_upload_g2", "dvn_bls12381_points_synthetic_g1", "dvn_bls12381_points_download",
-    "dvn_bls12381_scalars_synthetic", "dvn_bls12381_msm_g1", "dvn_bls12381_msm_g2", "dvn_bls12381_ntt_domain", "dvn_bls12381_ntt",
+    "dvn_bls12381_scalars_synthetic", "dvn_bls12381_msm_g1", "dvn_bls12381_msm_g2", "dvn_bls12381_ntt_domain", "dvn_bls12381_ntt", "dvn_bls12381_groth16_compute_h",
     "dvn_bw6761_points_upload", "dvn_bw6761_points_synthetic", "dvn_bw6761_points_download", "dvn_bw6761_scalars_synthetic", "dvn_bw6761_msm",
     "dvn_prover_use_gpu", "dvn_prover_set_use_gpu", "dvn_prover_reload_env", "dvn_prover_set_prover", "dvn_prover_set_cpu_backend",
     "dvn_prover_last_backend", "dvn_prover_prove", "dvn_prover_setup",
@@ -478,6 +480,13 @@ class Bls12377:
     def domain(self, log_n: int) -> Domain:
         p = C.c_void_p(); self.ctx._chk(self._f("ntt_domain")(self.ctx.h, log_n, C.byref(p)))
         return Domain(self.ctx, p, log_n)
+
+    def compute_h(self, dom: Domain, a: np.ndarray, b: np.ndarray, c: np.ndarray) -> np.ndarray:
+        """gnark computeH on host (len, 4) uint64 arrays; returns (n, 4), bit-reversed."""
+        a, b, c = (np.ascontiguousarray(x, dtype=np.uint64) for x in (a, b, c))
+        out = np.zeros((dom.n, 4), dtype=np.uint64)
+        self.ctx._chk(self._f("groth16_compute_h")(self.ctx.h, dom.handle, _host(a), _host(b), _host(c), a.shape[0], _host(out), 0))
+        return out
 
     def ntt(self, dom: Domain, data, inverse: bool, decimation: int, coset: bool = False):
         if isinstance(data, (int, np.integer)):

@@ -31,3 +31,7 @@ extern "C" int32_t dvn_bls12381_ntt_domain(dvn_ctx* ctx, uint32_t log_n, dvn_dom
 extern "C" int32_t dvn_bls12381_ntt(dvn_ctx* ctx, const dvn_domain* dom, uint64_t* data, int inverse, int decimation, int on_coset, uint32_t flags) {
     return suite_ntt<Fr381Cfg>(ctx, "BLS12-381", dom, data, inverse, decimation, on_coset, flags);
 }
+extern "C" int32_t dvn_bls12381_groth16_compute_h(dvn_ctx* ctx, const dvn_domain* dom, const uint64_t* a, const uint64_t* b, const uint64_t* c,
+                                                 size_t len, uint64_t* h_out, uint32_t flags) {
+    return compute_h_api<Fr381Cfg>(ctx, "BLS12-381", dom, a, b, c, len, h_out, flags);
+}

@@ -38,42 +38,10 @@ extern "C" int32_t dvn_ntt(dvn_ctx* ctx, const dvn_domain* dom, uint64_t* data, 
     return DVN_OK;
 }
 
-// computeH core on device buffers (gnark prove.go computeH): 3 x FFTInverse(DIF), 3 x FFT(DIT, coset),
-// pointwise (a*b - c) * den, FFTInverse(DIF, coset).  Result in da, bit-reversed.
-int32_t dvn_internal_compute_h_dev(dvn_ctx* ctx, const dvn_domain* dom, u32* da, u32* db, u32* dc) {
-    const size_t n = (size_t)1 << dom->log_n;
-    u32* v[3] = {da, db, dc};
-    for (int i = 0; i < 3; ++i) TRY(ntt_device<FrCfg>(ctx, dom, v[i], 1, DVN_DIF, 0));
-    for (int i = 0; i < 3; ++i) TRY(ntt_device<FrCfg>(ctx, dom, v[i], 0, DVN_DIT, 1));
-    k_h_pointwise<FrCfg><<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(da, db, dc, dom->h_consts, n);
-    HIP_TRY(hipGetLastError());
-    TRY(ntt_device<FrCfg>(ctx, dom, da, 1, DVN_DIF, 1));
-    return DVN_OK;
-}
+int32_t dvn_internal_compute_h_dev(dvn_ctx* ctx, const dvn_domain* dom, u32* da, u32* db, u32* dc) { return compute_h_device<FrCfg>(ctx, dom, da, db, dc); }
 uint32_t dvn_internal_domain_log_n(const dvn_domain* dom) { return dom->log_n; }
 
 extern "C" int32_t dvn_groth16_compute_h(dvn_ctx* ctx, const dvn_domain* dom, const uint64_t* a, const uint64_t* b, const uint64_t* c,
                                          size_t len, uint64_t* h_out, uint32_t flags) {
-    TRY(enter(ctx));
-    if (!dom || !a || !b || !c || !h_out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
-    const size_t n = (size_t)1 << dom->log_n;
-    if (len > n) return fail(DVN_ERR_INVALID_ARG, "len = %zu exceeds domain size %zu", len, n);
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    const bool on_dev = flags & DVN_NTT_DATA_ON_DEVICE;
-    const hipMemcpyKind in_kind = on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    TRY(ensure_ws(ctx, 3 * n * 32 + 1024));
-    u32* da = (u32*)ctx->ws; u32* db = da + n * 8; u32* dc = db + n * 8;
-    hipStream_t st = ctx->stream;
-    HIP_TRY(hipMemsetAsync(da, 0, 3 * n * 32, st));
-    HIP_TRY(hipMemcpyAsync(da, a, len * 32, in_kind, st));
-    HIP_TRY(hipMemcpyAsync(db, b, len * 32, in_kind, st));
-    HIP_TRY(hipMemcpyAsync(dc, c, len * 32, in_kind, st));
-    HIP_TRY(hipEventRecord(ctx->ev[0], st));
-    TRY(dvn_internal_compute_h_dev(ctx, dom, da, db, dc));
-    HIP_TRY(hipEventRecord(ctx->ev[1], st));
-    HIP_TRY(hipMemcpyAsync(h_out, da, n * 32, on_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipEventElapsedTime(&ctx->last_ms[0], ctx->ev[0], ctx->ev[1]));
-    ctx->last_ms[1] = ctx->last_ms[0];
-    return DVN_OK;
+    return compute_h_api<FrCfg>(ctx, "BN254", dom, a, b, c, len, h_out, flags);
 }

@@ -131,3 +131,43 @@ template <class S> static int32_t ntt_device(dvn_ctx* ctx, const dvn_domain* d, 
     }
     return DVN_OK;
 }
+
+// computeH core on device buffers (gnark prove.go computeH): 3 x FFTInverse(DIF), 3 x FFT(DIT, coset),
+// pointwise (a*b - c) * den, FFTInverse(DIF, coset).  Result in da, bit-reversed.  Caller holds ctx->mu.
+template <class S> static int32_t compute_h_device(dvn_ctx* ctx, const dvn_domain* dom, u32* da, u32* db, u32* dc) {
+    const size_t n = (size_t)1 << dom->log_n;
+    u32* v[3] = {da, db, dc};
+    for (int i = 0; i < 3; ++i) TRY(ntt_device<S>(ctx, dom, v[i], 1, DVN_DIF, 0));
+    for (int i = 0; i < 3; ++i) TRY(ntt_device<S>(ctx, dom, v[i], 0, DVN_DIT, 1));
+    k_h_pointwise<S><<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(da, db, dc, dom->h_consts, n);
+    HIP_TRY(hipGetLastError());
+    TRY(ntt_device<S>(ctx, dom, da, 1, DVN_DIF, 1));
+    return DVN_OK;
+}
+// the C-ABI entry (host or device a, b, c of `len` <= n elements, zero-padded): shared by every scalar field
+template <class S> static int32_t compute_h_api(dvn_ctx* ctx, const char* name, const dvn_domain* dom, const uint64_t* a, const uint64_t* b,
+                                                const uint64_t* c, size_t len, uint64_t* h_out, uint32_t flags) {
+    TRY(enter(ctx));
+    if (!dom || !a || !b || !c || !h_out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    if (dom->suite != DomainConsts<S>::SUITE) return fail(DVN_ERR_INVALID_ARG, "domain is not a %s domain", name);
+    const size_t n = (size_t)1 << dom->log_n;
+    if (len > n) return fail(DVN_ERR_INVALID_ARG, "len = %zu exceeds domain size %zu", len, n);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const bool on_dev = flags & DVN_NTT_DATA_ON_DEVICE;
+    const hipMemcpyKind in_kind = on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    TRY(ensure_ws(ctx, 3 * n * 32 + 1024));
+    u32* da = (u32*)ctx->ws; u32* db = da + n * 8; u32* dc = db + n * 8;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemsetAsync(da, 0, 3 * n * 32, st));
+    HIP_TRY(hipMemcpyAsync(da, a, len * 32, in_kind, st));
+    HIP_TRY(hipMemcpyAsync(db, b, len * 32, in_kind, st));
+    HIP_TRY(hipMemcpyAsync(dc, c, len * 32, in_kind, st));
+    HIP_TRY(hipEventRecord(ctx->ev[0], st));
+    TRY(compute_h_device<S>(ctx, dom, da, db, dc));
+    HIP_TRY(hipEventRecord(ctx->ev[1], st));
+    HIP_TRY(hipMemcpyAsync(h_out, da, n * 32, on_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipEventElapsedTime(&ctx->last_ms[0], ctx->ev[0], ctx->ev[1]));
+    ctx->last_ms[1] = ctx->last_ms[0];
+    return DVN_OK;
+}

@@ -212,6 +212,9 @@ int32_t dvn_bls12377_msm_g2(dvn_ctx* ctx, const dvn_points* pts, size_t off, siz
 int32_t dvn_bls12377_ntt_domain(dvn_ctx* ctx, uint32_t log_n, dvn_domain** out);      /* log_n <= 27 (two-adicity 47) */
 int32_t dvn_bls12377_ntt(dvn_ctx* ctx, const dvn_domain* dom, uint64_t* data, int inverse, int decimation, int on_coset,
                          uint32_t flags);
+/* computeH of gnark's backend/groth16/bls12-377/prove.go, same contract as dvn_groth16_compute_h */
+int32_t dvn_bls12377_groth16_compute_h(dvn_ctx* ctx, const dvn_domain* dom, const uint64_t* a, const uint64_t* b, const uint64_t* c,
+                                      size_t len, uint64_t* h_out, uint32_t flags);
 
 /* ---- BLS12-381 ------------------------------------------------------------------------------------ */
 /* The fourth curve of the reference's GPU dispatch (/root/reference/prover/prover_gpu.go:45-50) and the curve of the
@@ -230,6 +233,9 @@ int32_t dvn_bls12381_msm_g2(dvn_ctx* ctx, const dvn_points* pts, size_t off, siz
 int32_t dvn_bls12381_ntt_domain(dvn_ctx* ctx, uint32_t log_n, dvn_domain** out);      /* log_n <= 27 (two-adicity 32) */
 int32_t dvn_bls12381_ntt(dvn_ctx* ctx, const dvn_domain* dom, uint64_t* data, int inverse, int decimation, int on_coset,
                          uint32_t flags);
+/* computeH of gnark's backend/groth16/bls12-381/prove.go, same contract as dvn_groth16_compute_h */
+int32_t dvn_bls12381_groth16_compute_h(dvn_ctx* ctx, const dvn_domain* dom, const uint64_t* a, const uint64_t* b, const uint64_t* c,
+                                      size_t len, uint64_t* h_out, uint32_t flags);
 
 /* ---- BW6-761 -------------------------------------------------------------------------------------- */
 /* The aggregator's curve (/root/reference/spec/params/params.go:24; one proof per batch; reference GPU dispatch

@@ -247,6 +247,20 @@ class GenericDomain:
                 s = (s * pow(self.coset_inv, k, self.r)) % self.r
             a[i] = (a[i] * s) % self.r
 
+    def compute_h(self, a, bb, c):
+        """gnark groth16 computeH on this domain (bn254_py.compute_h, any scalar field): n values, bit-reversed."""
+        n, R = self.n, self.r
+        a = list(a) + [0] * (n - len(a)); bb = list(bb) + [0] * (n - len(bb)); c = list(c) + [0] * (n - len(c))
+        for v in (a, bb, c):
+            self.fft_inverse(v, b.DIF)
+        for v in (a, bb, c):
+            self.fft(v, b.DIT, coset=True)
+        den = pow((pow(self.coset, n, R) - 1) % R, -1, R)
+        for i in range(n):
+            a[i] = ((a[i] * bb[i] - c[i]) * den) % R
+        self.fft_inverse(a, b.DIF, coset=True)
+        return a
+
 
 _P377 = 0x01AE3A4617C510EAC63B05C06CA1493B1A22D9F300F5138F1EF3622FBA094800170B5D44300000008508C00000000001
 _R377 = 0x12AB655E9A2CA55660B44D1E5C37B00159AA76FED00000010A11800000000001

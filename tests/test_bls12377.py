@@ -204,6 +204,18 @@ def test_bls12377_ntt_all_modes_vs_oracle(bls, S, opy, log_n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("log_n,ln", [(3, 8), (6, 50), (9, 512)])
+def test_bls12377_compute_h_vs_oracle(bls, S, log_n, ln):
+    """computeH (3 iFFT, 3 coset FFT, pointwise, coset iFFT) on the curve's scalar field, ragged lengths zero-padded."""
+    dom = bls.domain(log_n); d = S.domain(1 << log_n)
+    a, b, c = ([S.fr_at(s, i) for i in range(ln)] for s in (11, 12, 13))
+    L = lambda v: np.array([S.fr_to_limbs(x) for x in v], dtype=np.uint64)
+    got = bls.compute_h(dom, L(a), L(b), L(c))
+    assert [S.fr_from_limbs(r) for r in got] == d.compute_h(a, b, c)
+    dom.free()
+
+
+@pytest.mark.gpu
 def test_bls12377_ntt_large_properties(bls, ctx, S, pkg):
     log_n = 20
     n = 1 << log_n
