@@ -100,6 +100,9 @@ def load_library():
         "dvn_bls12377_ntt_domain": (i32, [vp, u32, C.POINTER(vp)]),
         "dvn_bls12377_ntt": (i32, [vp, vp, vp, C.c_int, C.c_int, C.c_int, u32]),
         "dvn_bls12377_groth16_compute_h": (i32, [vp, vp, vp, vp, vp, sz, vp, u32]),
+        "dvn_bls12377_r1cs_synthetic": (i32, [u64, u32, u32, C.POINTER(vp)]),
+        "dvn_bls12377_groth16_setup": (i32, [vp, vp, u64, C.POINTER(vp)]),
+        "dvn_bls12377_groth16_prove": (i32, [vp, vp, vp, u32, vp, vp, vp]),
         "dvn_bls12381_points_upload_g1": (i32, [vp, vp, sz, C.POINTER(vp)]),
         "dvn_bls12381_points_upload_g2": (i32, [vp, vp, sz, C.POINTER(vp)]),
         "dvn_bls12381_points_synthetic_g1": (i32, [vp, u64, sz, C.POINTER(vp)]),
@@ -142,6 +145,7 @@ EXPORTED_SYMBOLS = [
     "dvn_groth16_proof_abi_encode", "dvn_pedersen_commit",
     "dvn_bls12377_points_upload_g1", "dvn_bls12377_points_upload_g2", "dvn_bls12377_points_synthetic_g1", "dvn_bls12377_points_download",
     "dvn_bls12377_scalars_synthetic", "dvn_bls12377_msm_g1", "dvn_bls12377_msm_g2", "dvn_bls12377_ntt_domain", "dvn_bls12377_ntt", "dvn_bls12377_groth16_compute_h",
+    "dvn_bls12377_r1cs_synthetic", "dvn_bls12377_groth16_setup", "dvn_bls12377_groth16_prove",
     "dvn_bls12381_points_upload_g1", "dvn_bls12381_points_upload_g2", "dvn_bls12381_points_synthetic_g1", "dvn_bls12381_points_download",
     "dvn_bls12381_scalars_synthetic", "dvn_bls12381_msm_g1", "dvn_bls12381_msm_g2", "dvn_bls12381_ntt_domain", "dvn_bls12381_ntt", "dvn_bls12381_groth16_compute_h",
     "dvn_bw6761_points_upload", "dvn_bw6761_points_synthetic", "dvn_bw6761_points_download", "dvn_bw6761_scalars_synthetic", "dvn_bw6761_msm",
@@ -373,10 +377,12 @@ class Context:
 class R1CS:
     """Host-side sparse R1CS handle (dvn_r1cs): the synthetic multiplication-gate instance of SURVEY.md §8d."""
 
-    def __init__(self, seed: int, n_constraints: int, n_public: int):
+    def __init__(self, seed: int, n_constraints: int, n_public: int, curve: str = "bn254"):
         self.L = load_library()
+        self.curve = curve
         h = C.c_void_p()
-        rc = self.L.dvn_r1cs_synthetic(seed, n_constraints, n_public, C.byref(h))
+        fn = self.L.dvn_r1cs_synthetic if curve == "bn254" else getattr(self.L, f"dvn_{curve}_r1cs_synthetic")
+        rc = fn(seed, n_constraints, n_public, C.byref(h))
         if rc != 0:
             raise DvnError(rc, self.L.dvn_last_error(None).decode())
         self.h = h
@@ -400,8 +406,11 @@ class Groth16Key:
 
     def __init__(self, ctx: Context, cs: R1CS, seed: int):
         self.ctx = ctx
+        self.curve = cs.curve
+        self._prefix = "dvn_" if cs.curve == "bn254" else f"dvn_{cs.curve}_"
+        self._a1 = 8 if cs.curve == "bn254" else 12           # uint64 words of a G1Affine image (G2Affine: twice that)
         h = C.c_void_p()
-        ctx._chk(ctx.L.dvn_groth16_setup(ctx.h, cs.h, seed, C.byref(h)))
+        ctx._chk(getattr(ctx.L, self._prefix + "groth16_setup")(ctx.h, cs.h, seed, C.byref(h)))
         self.h = h
         ln = C.c_uint32(); sizes = (C.c_uint64 * 5)()
         ctx.L.dvn_groth16_pk_info(h, C.byref(ln), sizes)
@@ -410,14 +419,15 @@ class Groth16Key:
 
     def prove(self, witness, r_mont: np.ndarray, s_mont: np.ndarray) -> dict:
         """witness: (m,4) uint64 host array or int device pointer.  Returns {'Ar': (8,), 'Bs': (16,), 'Krs': (8,)}."""
-        out = np.zeros(32, dtype=np.uint64)
+        a1 = self._a1
+        out = np.zeros(4 * a1, dtype=np.uint64)
         r_mont = np.ascontiguousarray(r_mont, dtype=np.uint64); s_mont = np.ascontiguousarray(s_mont, dtype=np.uint64)
         if isinstance(witness, (int, np.integer)):
             wp, fl = C.c_void_p(int(witness)), 1
         else:
             witness = np.ascontiguousarray(witness, dtype=np.uint64); wp, fl = _host(witness), 0
-        self.ctx._chk(self.ctx.L.dvn_groth16_prove(self.ctx.h, self.h, wp, fl, _host(r_mont), _host(s_mont), _host(out)))
-        return {"Ar": out[0:8].copy(), "Bs": out[8:24].copy(), "Krs": out[24:32].copy()}
+        self.ctx._chk(getattr(self.ctx.L, self._prefix + "groth16_prove")(self.ctx.h, self.h, wp, fl, _host(r_mont), _host(s_mont), _host(out)))
+        return {"Ar": out[0:a1].copy(), "Bs": out[a1:3 * a1].copy(), "Krs": out[3 * a1:4 * a1].copy()}
 
     def last_ms(self):
         a, b, c = C.c_float(), C.c_float(), C.c_float()

@@ -3,6 +3,7 @@
 // The same kernels as BN254, instantiated on 14-limb base-field elements (377 bits, external image 6 x u64,
 // R = 2^384), Fe2 with u^2 = -5 for G2, and the 253-bit scalar field (two-adicity 47, coset shift 22) for the NTT.
 #include "suite_api.h"
+#include "groth16_impl.h"
 
 static G1_377::A g1_377_generator() {      // gnark-crypto bls12-377 G1 generator, Montgomery image (oracle/curves_py.py BLS12_377.g1_gen)
     static const u64 g[12] = {0x260f33b9772451f4ULL, 0xc54dd773169d5658ULL, 0x5c1551c469a510ddULL, 0x761662e4425e1698ULL, 0xc97d78cc6f065272ULL, 0x00a41206b361fd4dULL,
@@ -33,4 +34,47 @@ extern "C" int32_t dvn_bls12377_ntt(dvn_ctx* ctx, const dvn_domain* dom, uint64_
 extern "C" int32_t dvn_bls12377_groth16_compute_h(dvn_ctx* ctx, const dvn_domain* dom, const uint64_t* a, const uint64_t* b, const uint64_t* c,
                                                  size_t len, uint64_t* h_out, uint32_t flags) {
     return compute_h_api<Fr377Cfg>(ctx, "BLS12-377", dom, a, b, c, len, h_out, flags);
+}
+
+// ---- Groth16 on BLS12-377 (the voteverifier proof, 60 per batch): groth16_impl.h over this curve's MSMs and computeH -----------
+// Synthetic Setup needs a generator of the r-torsion of the twist: [#E'(Fp2) / r] * Q for the smallest-x twist point Q
+// (oracle/curves_py.py BLS12_377.g2_gen; NOT gnark's generator -- production keys arrive through points_upload).
+static G2_377::A g2_377_generator() {
+    static const u64 g[24] = {
+        0x87e4cb96756a6edbULL, 0x99aa13a4fa9b9c4bULL, 0xd702cf5f38b86463ULL, 0x7ed4ce7924c167edULL, 0x1b447e91a9c5329fULL, 0x0084963f63a498b7ULL,
+        0x8554a79176a27e27ULL, 0xba4edb07f79e64a3ULL, 0xe2dc99bdfb15b037ULL, 0xe7d8740ff9d797f7ULL, 0x140c90e86aa2ea12ULL, 0x00cab5f295c622d3ULL,
+        0x2050bf7247d3ced4ULL, 0x67a8ee8100d17921ULL, 0x17d6f6cda3578307ULL, 0xd0eaa7550e0e26d8ULL, 0xf7aa721a161d7284ULL, 0x01604cec93c28ee1ULL,
+        0x4fc1f83c331faed0ULL, 0x6783c3d79d164e16ULL, 0x7ecc86be7de427ffULL, 0xbe7b613ac02526d5ULL, 0xb5eb2e9573178ceeULL, 0x00f5f8619a031dbfULL};
+    return G2_377::affine_from_ext((const u32*)g);
+}
+struct SuiteBls12377 {
+    typedef Fr377Cfg FrC;
+    typedef G1_377 G1T;
+    typedef G2_377 G2T;
+    typedef FastHost<G1_377>::G H1;
+    typedef FastHost<G2_377>::G H2;
+    static constexpr int SUITE = 1;
+    static const u32* r_words() { return R377_W; }
+    static G1_377::A g1_gen() { return g1_377_generator(); }
+    static G2_377::A g2_gen() { return g2_377_generator(); }
+    static int32_t domain_create(dvn_ctx* ctx, u32 log_n, dvn_domain** out) { return ntt_domain_create<Fr377Cfg>(ctx, log_n, out); }
+    static int32_t compute_h(dvn_ctx* ctx, const dvn_domain* dom, u32* a, u32* b, u32* c) { return compute_h_device<Fr377Cfg>(ctx, dom, a, b, c); }
+    static int32_t msm_submit_g1(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, MsmLane** l) {
+        return msm_submit<G1_377>(ctx, p, off, n, (const uint64_t*)s, DVN_MSM_SCALARS_ON_DEVICE, l);
+    }
+    static int32_t msm_submit_g2(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, MsmLane** l) {
+        return msm_submit<G2_377>(ctx, p, off, n, (const uint64_t*)s, DVN_MSM_SCALARS_ON_DEVICE, l);
+    }
+    static int32_t msm_collect_g1(dvn_ctx* ctx, MsmLane* l, H1::X* out) { return msm_collect<G1_377>(ctx, *l, out); }
+    static int32_t msm_collect_g2(dvn_ctx* ctx, MsmLane* l, H2::X* out) { return msm_collect<G2_377>(ctx, *l, out); }
+};
+extern "C" int32_t dvn_bls12377_r1cs_synthetic(uint64_t seed, uint32_t n_constraints, uint32_t n_public, dvn_r1cs** out) {
+    return r1cs_synthetic<SuiteBls12377>(seed, n_constraints, n_public, out);
+}
+extern "C" int32_t dvn_bls12377_groth16_setup(dvn_ctx* ctx, const dvn_r1cs* cs, uint64_t seed, dvn_groth16_pk** out) {
+    return groth16_setup<SuiteBls12377>(ctx, cs, seed, out);
+}
+extern "C" int32_t dvn_bls12377_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
+                                              const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[48]) {
+    return groth16_prove<SuiteBls12377>(ctx, pk, witness, flags, r_mont, s_mont, proof_out);
 }

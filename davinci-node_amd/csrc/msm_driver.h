@@ -494,7 +494,17 @@ template <class Cv> struct SlowHostG {
         if (Cv::is_inf(p)) { O::to_ext(O::one(), w); O::to_ext(O::one(), w + FW); O::to_ext(O::zero(), w + 2 * FW); return; }
         typename Cv::A a = Cv::to_affine(p);
         O::to_ext(a.x, w); O::to_ext(a.y, w + FW); O::to_ext(O::one(), w + 2 * FW);
+    }    // the O(1) finishing arithmetic of a proof (groth16_impl.h): k is a canonical 256-bit integer
+    static X mul_scalar(const X& p, const u32 k[8]) {
+        X acc = Cv::infinity();
+        for (int b = 255; b >= 0; --b) {
+            acc = Cv::dbl(acc);
+            if ((k[b >> 5] >> (b & 31)) & 1) acc = Cv::add(acc, p);
+        }
+        return acc;
     }
+    static X load_device_affine(const u32* w) { return Cv::from_affine(Cv::load_affine_internal(w)); }
+    static X normalize(const X& p) { return Cv::from_affine(Cv::to_affine(p)); }
 };
 template <class Cv> struct FastHost { typedef SlowHostG<Cv> G; };
 template <> struct FastHost<G1> { typedef dvn_host::HG1 G; };

@@ -216,6 +216,15 @@ int32_t dvn_bls12377_ntt(dvn_ctx* ctx, const dvn_domain* dom, uint64_t* data, in
 int32_t dvn_bls12377_groth16_compute_h(dvn_ctx* ctx, const dvn_domain* dom, const uint64_t* a, const uint64_t* b, const uint64_t* c,
                                       size_t len, uint64_t* h_out, uint32_t flags);
 
+/* Groth16 on BLS12-377 (the voteverifier proof: 60 per batch): the same Setup / Prove mirrors as dvn_groth16_setup /
+ * dvn_groth16_prove above, over this curve.  dvn_r1cs / dvn_groth16_pk handles remember their curve (mixing is rejected);
+ * dvn_r1cs_info / _witness / _free and dvn_groth16_pk_info / _pk_free / _last_ms apply to them as well.
+ * proof_out: Ar (12) | Bs (24) | Krs (12) uint64 = gnark's groth16_bls12377.Proof images. */
+int32_t dvn_bls12377_r1cs_synthetic(uint64_t seed, uint32_t n_constraints, uint32_t n_public, dvn_r1cs** out);
+int32_t dvn_bls12377_groth16_setup(dvn_ctx* ctx, const dvn_r1cs* cs, uint64_t seed, dvn_groth16_pk** out);
+int32_t dvn_bls12377_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
+                                   const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[48]);
+
 /* ---- BLS12-381 ------------------------------------------------------------------------------------ */
 /* The fourth curve of the reference's GPU dispatch (/root/reference/prover/prover_gpu.go:45-50) and the curve of the
  * EIP-4844 blob commitment computed before every state-transition proof: a 4096-point G1 MSM over the KZG setup in

@@ -269,6 +269,14 @@ BLS12_377 = Suite(
     g1_gen=(0x008848DEFE740A67C8FC6225BF87FF5485951E2CAA9D41BB188282C8BD37CB5CD5481512FFCD394EEAB9B16EB21BE9EF,
             0x01914A69C5102EFF1F674F5D30AFEEC4BD7FB348CA3E52D96D182AD44FB82305C2FE3D3634A9591AFD82DE55559C8EA6),
     fr_gen=22, two_adicity=47)
+# r-torsion generator of the BLS12-377 twist used by the library's SYNTHETIC Groth16 setup: [#E'(Fp2)/r] * (smallest-x twist point);
+# not gnark's generator (tests/test_groth16_curves.py re-derives it from the trace)
+BLS12_377.g2_gen = (
+    (0x6f72205595a839df693176b247c2fa251f7e02a29061e50540dc9e1c2bf1957bf1bab2288c257c2cb36b58f2418bc9,
+     0x138c24b2b4e17888beed0a9802aac837cdea39890effe00072f754ecb0152dd6cb524f281298966dbaeca23d3e462b8),
+    (0x16235fdea6c3faf2a83d3730f6ab2c033ef6c2739002946f7dc48e4688bca1af1c9b417d58220817e0dc644b5e7d916,
+     0x707ac6cc7d192827fc54eb83267f3bed8511bd3c74f63a1ea75eabb66476769c8786f2af2a75166f33142379b4963c))
+
 _P381 = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
 _R381 = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 # BLS12-381 (blob KZG; prover_gpu.go:45-50): y^2 = x^3 + 4, twist y^2 = x^3 + 4(1 + u), u^2 = -1, Fr generator 7
@@ -357,3 +365,65 @@ class Bw6761:
 
 
 BW6_761 = Bw6761()
+
+
+# --------------------------------------------------------------------------------------------------------
+# Synthetic Groth16 instance with a known trapdoor on any suite (bn254_py.SyntheticR1CS / groth16_* restated over suite.r)
+# --------------------------------------------------------------------------------------------------------
+class SuiteRng(b.SplitMix64):
+    def __init__(self, seed, r):
+        super().__init__(seed); self.r = r
+    def next_fr(self):
+        v = 0
+        for k in range(4):
+            v |= self.next() << (64 * k)
+        return v % self.r
+
+
+class SyntheticR1CSOn:
+    """n_c constraints (w[l1] + k w[l2]) * w[r] = w[o] over suite.r (dvn_<curve>_r1cs_synthetic)."""
+
+    def __init__(self, suite: Suite, n_constraints: int, n_public: int, seed: int):
+        R = suite.r
+        rng = SuiteRng(seed, R)
+        self.suite, self.n_public, self.n_constraints = suite, n_public, n_constraints
+        w = [1] + [rng.next_fr() for _ in range(n_public - 1)]
+        w += [rng.next_fr() for _ in range(4)]
+        self.A, self.B, self.C = [], [], []
+        for _ in range(n_constraints):
+            m = len(w)
+            l1 = rng.next() % m; l2 = rng.next() % m; k = rng.next() % 7 + 1; r_ = rng.next() % m
+            w.append(((w[l1] + k * w[l2]) * w[r_]) % R)
+            self.A.append([(l1, 1), (l2, k)] if l1 != l2 else [(l1, (1 + k) % R)])
+            self.B.append([(r_, 1)]); self.C.append([(m, 1)])
+        self.witness, self.n_wires = w, len(w)
+
+
+def groth16_expected_from_trapdoor_on(cs: SyntheticR1CSOn, seed: int, r: int, s: int):
+    """Closed-form proof (Ar, Bs, Krs) from the toxic waste of stream `seed` (tau, alpha, beta, gamma, delta)."""
+    S = cs.suite; R = S.r
+    rng = SuiteRng(seed, R)
+    tau, alpha, beta, gamma, delta = (rng.next_fr() or 1 for _ in range(5))
+    dom = S.domain(cs.n_constraints); n = dom.n
+    zt = (pow(tau, n, R) - 1) % R
+    L, wj = [], 1
+    for _ in range(n):
+        L.append(zt * wj % R * pow(n * (tau - wj) % R, -1, R) % R); wj = wj * dom.gen % R
+    m = cs.n_wires
+    At, Bt, Ct = [0] * m, [0] * m, [0] * m
+    for rows, acc in ((cs.A, At), (cs.B, Bt), (cs.C, Ct)):
+        for j, row in enumerate(rows):
+            for i, c in row:
+                acc[i] = (acc[i] + c * L[j]) % R
+    dinv = pow(delta, -1, R)
+    K = [((beta * At[i] + alpha * Bt[i] + Ct[i]) % R) * dinv % R for i in range(cs.n_public, m)]
+    w = cs.witness
+    a_tau = sum(wi * v for wi, v in zip(w, At)) % R
+    b_tau = sum(wi * v for wi, v in zip(w, Bt)) % R
+    c_tau = sum(wi * v for wi, v in zip(w, Ct)) % R
+    h_tau = (a_tau * b_tau - c_tau) * pow(zt, -1, R) % R
+    ar = (alpha + a_tau + r * delta) % R
+    bs = (beta + b_tau + s * delta) % R
+    priv = sum(w[cs.n_public + i] * k for i, k in enumerate(K)) % R
+    krs = (priv + h_tau * zt % R * dinv + s * ar + r * bs - r * s % R * delta) % R
+    return {"Ar": S.g1_mul(S.g1_gen, ar), "Bs": S.g2_mul(S.g2_gen, bs), "Krs": S.g1_mul(S.g1_gen, krs)}

@@ -1,0 +1,66 @@
+"""Groth16 on the voteverifier curve (BLS12-377): the curve-generic Setup / Prove mirrors
+(csrc/groth16_impl.h) against the closed form a known trapdoor gives (oracle/curves_py.py).  Parity unpinned by the
+reference (no vectors); the trapdoor identity is exact: Ar = [alpha + A(tau) + r delta] G1 etc."""
+from math import isqrt
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def S():
+    from oracle import curves_py
+    return curves_py.BLS12_377
+
+
+def test_bls12377_g2_generator_is_r_torsion(S):
+    """The synthetic setup's twist generator: re-derive [#E'(Fp2)/r] * Q from the curve's trace."""
+    p, r = S.p, S.r
+    x = 0x8508C00000000001                                   # the BLS12-377 seed: t = x + 1
+    t = x + 1
+    assert (p + 1 - t) % r == 0
+    t2 = t * t - 2 * p
+    f2 = isqrt((4 * p * p - t2 * t2) // 3)
+    assert 3 * f2 * f2 == 4 * p * p - t2 * t2
+    n_twist = p * p + 1 - (t2 - 3 * f2) // 2
+    assert n_twist % r == 0
+    q = S.g2_some_point(1)
+    assert S.g2_mul(q, n_twist) is None                      # the order of the twist really is n_twist
+    g = S.g2_mul(q, n_twist // r)
+    assert g == S.g2_gen and S.g2_on_curve(g) and S.g2_mul(g, r) is None
+
+
+def test_generic_oracle_matches_bn254_oracle(opy):
+    """curves_py's suite-generic trapdoor proof == bn254_py's on BN254 (same streams, same closed form)."""
+    from oracle import curves_py as cp
+    cp.BN254.g2_gen = opy.G2_GEN
+    cs_g = cp.SyntheticR1CSOn(cp.BN254, 20, 3, 7)
+    cs_b = opy.SyntheticR1CS(20, 3, 7)
+    assert cs_g.witness == cs_b.witness and cs_g.A == cs_b.A
+    pk, trap = opy.groth16_setup(cs_b, 9)
+    want = opy.groth16_expected_from_trapdoor(cs_b, trap, pk["domain"], 5, 11)
+    got = cp.groth16_expected_from_trapdoor_on(cs_g, 9, 5, 11)
+    assert got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_constraints,n_public", [(5, 1), (300, 3), (5000, 2)])
+def test_bls12377_groth16_trapdoor_identity(ctx, pkg, S, n_constraints, n_public):
+    from oracle import curves_py as cp
+    cs = pkg.R1CS(3, n_constraints, n_public, curve="bls12377")
+    ocs = cp.SyntheticR1CSOn(S, n_constraints, n_public, 3)
+    w = cs.witness()
+    assert cs.n_wires == ocs.n_wires
+    assert [S.fr_from_limbs(x) for x in w[:50]] == ocs.witness[:50]
+    key = pkg.Groth16Key(ctx, cs, 9)
+    for r, s in ((5, 11), (S.fr_at(1, 0), S.fr_at(1, 1))):
+        proof = key.prove(w, np.array(S.fr_to_limbs(r), dtype=np.uint64), np.array(S.fr_to_limbs(s), dtype=np.uint64))
+        want = cp.groth16_expected_from_trapdoor_on(ocs, 9, r, s)
+        assert list(proof["Ar"]) == S.g1_to_limbs(want["Ar"])
+        assert list(proof["Bs"]) == S.g2_to_limbs(want["Bs"])
+        assert list(proof["Krs"]) == S.g1_to_limbs(want["Krs"])
+    # a BN254 constraint system is rejected by this curve's setup, and vice versa
+    cs_bn = pkg.R1CS(3, 10, 1)
+    with pytest.raises(pkg.DvnError):
+        ctx._chk(ctx.L.dvn_bls12377_groth16_setup(ctx.h, cs_bn.h, 9, __import__("ctypes").byref(__import__("ctypes").c_void_p())))
+    cs_bn.free(); key.free(); cs.free()
