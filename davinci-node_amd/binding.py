@@ -113,6 +113,10 @@ def load_library():
         "dvn_bls12381_ntt_domain": (i32, [vp, u32, C.POINTER(vp)]),
         "dvn_bls12381_ntt": (i32, [vp, vp, vp, C.c_int, C.c_int, C.c_int, u32]),
         "dvn_bls12381_groth16_compute_h": (i32, [vp, vp, vp, vp, vp, sz, vp, u32]),
+        "dvn_bls12381_r1cs_synthetic": (i32, [u64, u32, u32, C.POINTER(vp)]),
+        "dvn_bls12381_groth16_setup": (i32, [vp, vp, u64, C.POINTER(vp)]),
+        "dvn_bls12381_groth16_prove": (i32, [vp, vp, vp, u32, vp, vp, vp]),
+        "dvn_r1cs_curve": (i32, [vp]),
         "dvn_bw6761_points_upload": (i32, [vp, C.c_int, vp, sz, C.POINTER(vp)]),
         "dvn_bw6761_points_synthetic": (i32, [vp, C.c_int, vp, u64, sz, C.POINTER(vp)]),
         "dvn_bw6761_points_download": (i32, [vp, vp, sz, sz, vp]),
@@ -148,6 +152,7 @@ EXPORTED_SYMBOLS = [
     "dvn_bls12377_r1cs_synthetic", "dvn_bls12377_groth16_setup", "dvn_bls12377_groth16_prove",
     "dvn_bls12381_points_upload_g1", "dvn_bls12381_points_upload_g2", "dvn_bls12381_points_synthetic_g1", "dvn_bls12381_points_download",
     "dvn_bls12381_scalars_synthetic", "dvn_bls12381_msm_g1", "dvn_bls12381_msm_g2", "dvn_bls12381_ntt_domain", "dvn_bls12381_ntt", "dvn_bls12381_groth16_compute_h",
+    "dvn_bls12381_r1cs_synthetic", "dvn_bls12381_groth16_setup", "dvn_bls12381_groth16_prove", "dvn_r1cs_curve",
     "dvn_bw6761_points_upload", "dvn_bw6761_points_synthetic", "dvn_bw6761_points_download", "dvn_bw6761_scalars_synthetic", "dvn_bw6761_msm",
     "dvn_prover_use_gpu", "dvn_prover_set_use_gpu", "dvn_prover_reload_env", "dvn_prover_set_prover", "dvn_prover_set_cpu_backend",
     "dvn_prover_last_backend", "dvn_prover_prove", "dvn_prover_setup",

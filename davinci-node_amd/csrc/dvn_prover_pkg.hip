@@ -6,8 +6,8 @@
 //   prover/prover_gpu.go:66  Prove                   prover::Prove            -> prover(...)
 //   prover/prover_gpu.go:71  defaultProver           prover::defaultProver    GPU, on ANY error print + CPU fallback
 //   prover/prover_gpu.go:87  CPUProver(+WithWitness) prover::CPUProver        -> the registered CPU backend (gnark in production)
-//   prover/prover_gpu.go:99  GPUProver(+WithWitness) prover::GPUProver        -> callGPUProver: per-curve dispatch, BN254 only
-//   prover/prover_gpu.go:24  callGPUProver           prover::callGPUProver    other curves: "GPU proving not supported for curve"
+//   prover/prover_gpu.go:99  GPUProver(+WithWitness) prover::GPUProver        -> callGPUProver: per-curve dispatch
+//   prover/prover_gpu.go:24  callGPUProver           prover::callGPUProver    BN254, BLS12_377, BLS12_381; BW6_761: "GPU proving not supported for curve"
 //   prover/setup.go:15       Setup                   prover::Setup            -> dvn_groth16_setup, timing log
 // The CPU prover is NOT part of this library: in the node it is gnark's groth16.Prove.  CPUProver therefore calls a
 // backend registered by the embedder (dvn_prover_set_cpu_backend); with none registered it returns an error -- it never
@@ -50,7 +50,13 @@ int32_t callGPUProver(const Request* q) {
         case BN254:
             if (!q->pk) return fail(DVN_ERR_INVALID_ARG, "proving key type mismatch for BN254: expected a device-resident dvn_groth16_pk, got NULL");
             return dvn_groth16_prove(q->ctx, q->pk, q->witness, 0, q->r, q->s, q->proof);
-        default:
+        case BLS12_377:          // the reference also sets PinToGPU here (prover_gpu.go:41): keys are always device-resident in this library
+            if (!q->pk) return fail(DVN_ERR_INVALID_ARG, "proving key type mismatch for BLS12_377: expected a device-resident dvn_groth16_pk, got NULL");
+            return dvn_bls12377_groth16_prove(q->ctx, q->pk, q->witness, 0, q->r, q->s, q->proof);
+        case BLS12_381:
+            if (!q->pk) return fail(DVN_ERR_INVALID_ARG, "proving key type mismatch for BLS12_381: expected a device-resident dvn_groth16_pk, got NULL");
+            return dvn_bls12381_groth16_prove(q->ctx, q->pk, q->witness, 0, q->r, q->s, q->proof);
+        default:                 // BW6_761: MSM only so far (no scalar-field NTT) -> the caller falls back to the CPU prover
             return fail(DVN_ERR_UNSUPPORTED, "GPU proving not supported for curve %s", curve_name(q->curve));
     }
 }
@@ -82,7 +88,9 @@ int32_t Setup(dvn_ctx* ctx, const dvn_r1cs* ccs, uint64_t seed, dvn_groth16_pk**
     uint32_t nc = 0; dvn_r1cs_info(ccs, nullptr, nullptr, &nc);
     fprintf(stderr, "[prover] generating circuit keys gpu=%s constraints=%u\n", UseGPUProver ? "true" : "false", nc);
     auto t0 = std::chrono::steady_clock::now();
-    int32_t rc = dvn_groth16_setup(ctx, ccs, seed, pk);
+    const int32_t cid = dvn_r1cs_curve(ccs);
+    int32_t rc = cid == BLS12_377 ? dvn_bls12377_groth16_setup(ctx, ccs, seed, pk) : cid == BLS12_381 ? dvn_bls12381_groth16_setup(ctx, ccs, seed, pk)
+                                    : dvn_groth16_setup(ctx, ccs, seed, pk);
     if (rc == DVN_OK) {
         double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         fprintf(stderr, "[prover] circuit keys setup done took=%.3fs gpu=%s constraints=%u\n", s, UseGPUProver ? "true" : "false", nc);

@@ -140,6 +140,8 @@ int32_t dvn_groth16_compute_h(dvn_ctx* ctx, const dvn_domain* dom, const uint64_
 typedef struct dvn_r1cs dvn_r1cs;
 typedef struct dvn_groth16_pk dvn_groth16_pk;
 int32_t dvn_r1cs_synthetic(uint64_t seed, uint32_t n_constraints, uint32_t n_public, dvn_r1cs** out);
+/* gnark ecc.ID of the system's curve as the prover mirror numbers them: 1 BN254, 2 BLS12_377, 3 BLS12_381 */
+int32_t dvn_r1cs_curve(const dvn_r1cs* cs);
 int32_t dvn_r1cs_info(const dvn_r1cs* cs, uint32_t* n_wires, uint32_t* n_public, uint32_t* n_constraints);
 int32_t dvn_r1cs_witness(const dvn_r1cs* cs, uint64_t* out /* n_wires x 4, Montgomery */);
 void dvn_r1cs_free(dvn_r1cs* cs);
@@ -245,6 +247,11 @@ int32_t dvn_bls12381_ntt(dvn_ctx* ctx, const dvn_domain* dom, uint64_t* data, in
 /* computeH of gnark's backend/groth16/bls12-381/prove.go, same contract as dvn_groth16_compute_h */
 int32_t dvn_bls12381_groth16_compute_h(dvn_ctx* ctx, const dvn_domain* dom, const uint64_t* a, const uint64_t* b, const uint64_t* c,
                                       size_t len, uint64_t* h_out, uint32_t flags);
+
+int32_t dvn_bls12381_r1cs_synthetic(uint64_t seed, uint32_t n_constraints, uint32_t n_public, dvn_r1cs** out);
+int32_t dvn_bls12381_groth16_setup(dvn_ctx* ctx, const dvn_r1cs* cs, uint64_t seed, dvn_groth16_pk** out);
+int32_t dvn_bls12381_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
+                                   const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[48]);
 
 /* ---- BW6-761 -------------------------------------------------------------------------------------- */
 /* The aggregator's curve (/root/reference/spec/params/params.go:24; one proof per batch; reference GPU dispatch

@@ -1,4 +1,4 @@
-"""Groth16 on the voteverifier curve (BLS12-377): the curve-generic Setup / Prove mirrors
+"""Groth16 on the voteverifier curve (BLS12-377) and on BLS12-381 (prover_gpu.go:45-50): the curve-generic Setup / Prove mirrors
 (csrc/groth16_impl.h) against the closed form a known trapdoor gives (oracle/curves_py.py).  Parity unpinned by the
 reference (no vectors); the trapdoor identity is exact: Ar = [alpha + A(tau) + r delta] G1 etc."""
 from math import isqrt
@@ -7,14 +7,24 @@ import numpy as np
 import pytest
 
 
-@pytest.fixture(scope="module")
-def S():
+@pytest.fixture(scope="module", params=["bls12377", "bls12381"])
+def S(request):
     from oracle import curves_py
-    return curves_py.BLS12_377
+    s = curves_py.BLS12_377 if request.param == "bls12377" else curves_py.BLS12_381
+    s.cname = request.param
+    return s
 
 
-def test_bls12377_g2_generator_is_r_torsion(S):
+def test_bls12381_g2_generator_is_r_torsion():
+    from oracle import curves_py
+    S = curves_py.BLS12_381
+    assert S.g2_on_curve(S.g2_gen) and S.g2_mul(S.g2_gen, S.r) is None
+
+
+def test_bls12377_g2_generator_is_r_torsion():
     """The synthetic setup's twist generator: re-derive [#E'(Fp2)/r] * Q from the curve's trace."""
+    from oracle import curves_py
+    S = curves_py.BLS12_377
     p, r = S.p, S.r
     x = 0x8508C00000000001                                   # the BLS12-377 seed: t = x + 1
     t = x + 1
@@ -45,9 +55,9 @@ def test_generic_oracle_matches_bn254_oracle(opy):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_constraints,n_public", [(5, 1), (300, 3), (5000, 2)])
-def test_bls12377_groth16_trapdoor_identity(ctx, pkg, S, n_constraints, n_public):
+def test_groth16_trapdoor_identity_other_curves(ctx, pkg, S, n_constraints, n_public):
     from oracle import curves_py as cp
-    cs = pkg.R1CS(3, n_constraints, n_public, curve="bls12377")
+    cs = pkg.R1CS(3, n_constraints, n_public, curve=S.cname)
     ocs = cp.SyntheticR1CSOn(S, n_constraints, n_public, 3)
     w = cs.witness()
     assert cs.n_wires == ocs.n_wires
@@ -62,5 +72,5 @@ def test_bls12377_groth16_trapdoor_identity(ctx, pkg, S, n_constraints, n_public
     # a BN254 constraint system is rejected by this curve's setup, and vice versa
     cs_bn = pkg.R1CS(3, 10, 1)
     with pytest.raises(pkg.DvnError):
-        ctx._chk(ctx.L.dvn_bls12377_groth16_setup(ctx.h, cs_bn.h, 9, __import__("ctypes").byref(__import__("ctypes").c_void_p())))
+        ctx._chk(getattr(ctx.L, f"dvn_{S.cname}_groth16_setup")(ctx.h, cs_bn.h, 9, __import__("ctypes").byref(__import__("ctypes").c_void_p())))
     cs_bn.free(); key.free(); cs.free()

@@ -126,3 +126,30 @@ def test_gpu_prover_and_forced_failure_fallback(L, ctx, pkg, opy, orc, capfd):
     assert calls == [1] and (out2 == out).all()                       # CPU backend result equals the GPU proof
     bad.close()
     L.dvn_groth16_pk_free(ctx.h, pk); cs.free()
+
+
+@pytest.mark.gpu
+def test_prover_mirror_dispatches_bls12377_to_the_gpu(L, ctx, pkg, capfd):
+    """prover_gpu.go:36-43: ecc.BLS12_377 has a GPU leg.  Setup picks the curve from the constraint system, Prove runs on the
+    device (backend 1) and yields the trapdoor proof; a key of the wrong curve is an error -> CPU fallback message."""
+    from oracle import curves_py as cp
+    S = cp.BLS12_377
+    cs = pkg.R1CS(3, 200, 2, curve="bls12377")
+    assert L.dvn_r1cs_curve(cs.h) == 2
+    pk = C.c_void_p()
+    assert L.dvn_prover_setup(ctx.h, cs.h, 9, C.byref(pk)) == 0
+    L.dvn_prover_set_prover(None, None)
+    L.dvn_prover_set_use_gpu(1)
+    out = np.zeros(48, dtype=np.uint64); w = cs.witness()
+    r = np.array(S.fr_to_limbs(5), dtype=np.uint64); s = np.array(S.fr_to_limbs(11), dtype=np.uint64)
+    assert L.dvn_prover_prove(ctx.h, 2, cs.h, pk, w.ctypes.data, r.ctypes.data, s.ctypes.data, out.ctypes.data) == 0
+    assert L.dvn_prover_last_backend() == 1
+    want = cp.groth16_expected_from_trapdoor_on(cp.SyntheticR1CSOn(S, 200, 2, 3), 9, 5, 11)
+    assert list(out[0:12]) == S.g1_to_limbs(want["Ar"]) and list(out[12:36]) == S.g2_to_limbs(want["Bs"]) and list(out[36:48]) == S.g1_to_limbs(want["Krs"])
+    # the BLS12-377 key handed to the BN254 leg: type mismatch -> fallback (no CPU backend registered -> error code)
+    L.dvn_prover_set_cpu_backend(None, None)
+    assert L.dvn_prover_prove(ctx.h, 1, cs.h, pk, w.ctypes.data, r.ctypes.data, s.ctypes.data, out.ctypes.data) != 0
+    assert "GPU proving failed (" in capfd.readouterr().out
+    L.dvn_prover_set_use_gpu(0)
+    assert L.dvn_groth16_pk_free(ctx.h, pk) == 0
+    cs.free()
