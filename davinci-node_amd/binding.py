@@ -122,6 +122,9 @@ def load_library():
         "dvn_bw6761_points_download": (i32, [vp, vp, sz, sz, vp]),
         "dvn_bw6761_scalars_synthetic": (i32, [vp, u64, C.c_int, sz, vp]),
         "dvn_bw6761_msm": (i32, [vp, vp, sz, sz, vp, u32, vp]),
+        "dvn_bw6761_ntt_domain": (i32, [vp, u32, C.POINTER(vp)]),
+        "dvn_bw6761_ntt": (i32, [vp, vp, vp, C.c_int, C.c_int, C.c_int, u32]),
+        "dvn_bw6761_groth16_compute_h": (i32, [vp, vp, vp, vp, vp, sz, vp, u32]),
         "dvn_prover_use_gpu": (i32, []),
         "dvn_prover_set_use_gpu": (None, [i32]),
         "dvn_prover_reload_env": (None, []),
@@ -154,6 +157,7 @@ EXPORTED_SYMBOLS = [
     "dvn_bls12381_scalars_synthetic", "dvn_bls12381_msm_g1", "dvn_bls12381_msm_g2", "dvn_bls12381_ntt_domain", "dvn_bls12381_ntt", "dvn_bls12381_groth16_compute_h",
     "dvn_bls12381_r1cs_synthetic", "dvn_bls12381_groth16_setup", "dvn_bls12381_groth16_prove", "dvn_r1cs_curve",
     "dvn_bw6761_points_upload", "dvn_bw6761_points_synthetic", "dvn_bw6761_points_download", "dvn_bw6761_scalars_synthetic", "dvn_bw6761_msm",
+    "dvn_bw6761_ntt_domain", "dvn_bw6761_ntt", "dvn_bw6761_groth16_compute_h",
     "dvn_prover_use_gpu", "dvn_prover_set_use_gpu", "dvn_prover_reload_env", "dvn_prover_set_prover", "dvn_prover_set_cpu_backend",
     "dvn_prover_last_backend", "dvn_prover_prove", "dvn_prover_setup",
 ]
@@ -554,4 +558,23 @@ class Bw6761:
             sp, ns, fl = _host(scalars), scalars.shape[0], 0
         out = np.zeros(36, dtype=np.uint64)
         self.ctx._chk(self.L.dvn_bw6761_msm(self.ctx.h, pts.handle, off, ns, sp, fl, _host(out)))
+        return out
+
+    def domain(self, log_n: int) -> Domain:
+        p = C.c_void_p(); self.ctx._chk(self.L.dvn_bw6761_ntt_domain(self.ctx.h, log_n, C.byref(p)))
+        return Domain(self.ctx, p, log_n)
+
+    def ntt(self, dom: Domain, data, inverse: bool, decimation: int, coset: bool = False):
+        """data: (n, 6) uint64 host array (in place) or a device pointer."""
+        if isinstance(data, (int, np.integer)):
+            self.ctx._chk(self.L.dvn_bw6761_ntt(self.ctx.h, dom.handle, C.c_void_p(int(data)), int(inverse), decimation, int(coset), NTT_DATA_ON_DEVICE))
+            return data
+        assert data.dtype == np.uint64 and data.flags["C_CONTIGUOUS"] and data.shape == (dom.n, 6)
+        self.ctx._chk(self.L.dvn_bw6761_ntt(self.ctx.h, dom.handle, _host(data), int(inverse), decimation, int(coset), 0))
+        return data
+
+    def compute_h(self, dom: Domain, a: np.ndarray, b: np.ndarray, c: np.ndarray) -> np.ndarray:
+        a, b, c = (np.ascontiguousarray(x, dtype=np.uint64) for x in (a, b, c))
+        out = np.zeros((dom.n, 6), dtype=np.uint64)
+        self.ctx._chk(self.L.dvn_bw6761_groth16_compute_h(self.ctx.h, dom.handle, _host(a), _host(b), _host(c), a.shape[0], _host(out), 0))
         return out

@@ -6,7 +6,7 @@
 // limbs the column accumulators of a product take 108 registers, so the field multiplication is a real call
 // (Ops<Fe<C>>::CALL_MUL) and the lazily reduced accumulator formulas are off (three products per column would
 // overflow 64 bits).
-#include "msm_driver.h"
+#include "suite_api.h"
 
 static int32_t check_group(int group) { return (group == 1 || group == 2) ? DVN_OK : fail(DVN_ERR_INVALID_ARG, "group must be 1 (G1) or 2 (G2)"); }
 
@@ -54,4 +54,13 @@ extern "C" int32_t dvn_bw6761_scalars_synthetic(dvn_ctx* ctx, uint64_t seed, int
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return DVN_OK;
+}
+// ---- the scalar field's NTT (377-bit elements: 6 x uint64, two-adicity 46, coset shift 15) and computeH ------------------
+extern "C" int32_t dvn_bw6761_ntt_domain(dvn_ctx* ctx, uint32_t log_n, dvn_domain** out) { return ntt_domain_create<Fp377Cfg>(ctx, log_n, out); }
+extern "C" int32_t dvn_bw6761_ntt(dvn_ctx* ctx, const dvn_domain* dom, uint64_t* data, int inverse, int decimation, int on_coset, uint32_t flags) {
+    return suite_ntt<Fp377Cfg>(ctx, "BW6-761", dom, data, inverse, decimation, on_coset, flags);
+}
+extern "C" int32_t dvn_bw6761_groth16_compute_h(dvn_ctx* ctx, const dvn_domain* dom, const uint64_t* a, const uint64_t* b, const uint64_t* c,
+                                                size_t len, uint64_t* h_out, uint32_t flags) {
+    return compute_h_api<Fp377Cfg>(ctx, "BW6-761", dom, a, b, c, len, h_out, flags);
 }

@@ -18,24 +18,29 @@ template <> struct DomainConsts<Fr381Cfg> {   // w_{2^32} = 7^((r-1)/2^32) = 102
     static constexpr u32 ADICITY = 32; static constexpr u64 COSET_GEN = 7; static constexpr int SUITE = 3;
     static const u64* root() { static const u64 r[4] = {0x3829971f439f0d2bULL, 0xb63683508c2280b9ULL, 0xd09b681922c813b4ULL, 0x16a2a19edfe81f20ULL}; return r; }
 };
+template <> struct DomainConsts<Fp377Cfg> {   // BW6-761's scalar field: w_{2^46} = 15^((r-1)/2^46) = gnark-crypto's
+    // 32863578547254505029601261939868325669770508939375122462904745766352256812585773382134936404344547323199885654433
+    static constexpr u32 ADICITY = 46; static constexpr u64 COSET_GEN = 15; static constexpr int SUITE = 2;
+    static const u64* root() { static const u64 r[6] = {0x7eca603cc563b9a1ULL, 0x06df0a4306fe0bc3ULL, 0xb44d994a0ddff8c6ULL, 0x40fbe05b4512a3d4ULL, 0x30f152488aeffc9bULL, 0x0036a92e05198a80ULL}; return r; }
+};
 
 // ------------------------------------------------------------------------------------------------------
 // NTT
 // ------------------------------------------------------------------------------------------------------
 template <class S> static Fe<S> fr_from_u64(u64 v) {
-    u32 w[8] = {(u32)v, (u32)(v >> 32), 0, 0, 0, 0, 0, 0};
+    u32 w[S::EW] = {(u32)v, (u32)(v >> 32)};
     return fe_from_canonical<S>(fe_unpack<S>(w));
 }
 template <class S> static Fe<S> fr_root_of_unity(u32 log_n) {      // square the 2-adic root down to order 2^log_n
-    Fe<S> w = fe_from_canonical<S>(fe_unpack<S>(*(const u32(*)[8])DomainConsts<S>::root()));
+    Fe<S> w = fe_from_canonical<S>(fe_unpack<S>(*(const u32(*)[S::EW])DomainConsts<S>::root()));
     for (u32 i = log_n; i < DomainConsts<S>::ADICITY; ++i) w = fe_sqr<S>(w);
     return w;
 }
-template <class S> static void fr_store_internal(const Fe<S>& v, u32* w) { u32 t[8]; fe_pack<S>(fe_canonical<S>(v), t); memcpy(w, t, 32); }
+template <class S> static void fr_store_internal(const Fe<S>& v, u32* w) { u32 t[S::EW]; fe_pack<S>(fe_canonical<S>(v), t); memcpy(w, t, S::EW * 4); }
 
 template <class S> static int32_t launch_powers(dvn_ctx* ctx, u32* d_out, const Fe<S>& base, const Fe<S>& first, size_t count, u32* d_scratch16) {
-    u32 h[16]; fr_store_internal<S>(base, h); fr_store_internal<S>(first, h + 8);
-    HIP_TRY(hipMemcpyAsync(d_scratch16, h, 64, hipMemcpyHostToDevice, ctx->stream));
+    u32 h[2 * S::EW]; fr_store_internal<S>(base, h); fr_store_internal<S>(first, h + S::EW);
+    HIP_TRY(hipMemcpyAsync(d_scratch16, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
     const u32 chunk = 64;
     size_t threads = (count + chunk - 1) / chunk;
     k_powers<S><<<(unsigned)((threads + 63) / 64), 64, 0, ctx->stream>>>(d_out, d_scratch16, count, chunk);
@@ -57,7 +62,7 @@ template <class S> static int32_t ntt_domain_create(dvn_ctx* ctx, uint32_t log_n
     const size_t nlo = (size_t)1 << d->lo_bits, nhi = n >> d->lo_bits;
     u32* scratch = nullptr;
     int32_t rc = DVN_OK;
-    auto alloc = [&](u32** p, size_t entries) -> int32_t { HIP_TRY(hipMalloc((void**)p, entries * 32)); return DVN_OK; };
+    auto alloc = [&](u32** p, size_t entries) -> int32_t { HIP_TRY(hipMalloc((void**)p, entries * S::EW * 4)); return DVN_OK; };
     do {
         if ((rc = alloc(&d->tw_fwd, n)) || (rc = alloc(&d->tw_inv, n)) || (rc = alloc(&d->g_lo, nlo)) || (rc = alloc(&d->g_hi, nhi)) ||
             (rc = alloc(&d->gi_lo, nlo)) || (rc = alloc(&d->gi_hi, nhi)) || (rc = alloc(&d->card_inv, 1)) || (rc = alloc(&d->h_consts, 2)) ||
@@ -67,8 +72,8 @@ template <class S> static int32_t ntt_domain_create(dvn_ctx* ctx, uint32_t log_n
         Fe<S> ws = w, wis = wi;
         for (u32 s = 0; s < log_n && rc == DVN_OK; ++s) {
             const size_t half = n >> (s + 1), offs = n - (n >> s);
-            if ((rc = launch_powers<S>(ctx, d->tw_fwd + offs * 8, ws, one, half, scratch))) break;
-            if ((rc = launch_powers<S>(ctx, d->tw_inv + offs * 8, wis, one, half, scratch))) break;
+            if ((rc = launch_powers<S>(ctx, d->tw_fwd + offs * S::EW, ws, one, half, scratch))) break;
+            if ((rc = launch_powers<S>(ctx, d->tw_inv + offs * S::EW, wis, one, half, scratch))) break;
             ws = fe_sqr<S>(ws); wis = fe_sqr<S>(wis);
         }
         if (rc) break;
@@ -77,14 +82,15 @@ template <class S> static int32_t ntt_domain_create(dvn_ctx* ctx, uint32_t log_n
         if ((rc = launch_powers<S>(ctx, d->g_hi, fe_pow_u64<S>(g, nlo), one, nhi, scratch))) break;
         if ((rc = launch_powers<S>(ctx, d->gi_lo, gi, ninv, nlo, scratch))) break;
         if ((rc = launch_powers<S>(ctx, d->gi_hi, fe_pow_u64<S>(gi, nlo), one, nhi, scratch))) break;
-        u32 h[24];
+        constexpr u32 EW = S::EW;
+        u32 h[3 * EW];
         fr_store_internal<S>(ninv, h);
         // den = 1/(g^n - 1); k1 = den * 2^5 (internal), k2 = den
         const Fe<S> den = fe_inv<S>(fe_sub<S>(fe_pow_u64<S>(g, n), one));
-        fr_store_internal<S>(fe_mul<S>(den, fr_from_u64<S>(1u << S::EXT_SHIFT)), h + 8);
-        fr_store_internal<S>(den, h + 16);
-        hipError_t e = hipMemcpy(d->card_inv, h, 32, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(d->h_consts, h + 8, 64, hipMemcpyHostToDevice);
+        fr_store_internal<S>(fe_mul<S>(den, fr_from_u64<S>(1u << S::EXT_SHIFT)), h + EW);
+        fr_store_internal<S>(den, h + 2 * EW);
+        hipError_t e = hipMemcpy(d->card_inv, h, EW * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d->h_consts, h + EW, 2 * EW * 4, hipMemcpyHostToDevice);
         if (e != hipSuccess) { (void)hipGetLastError(); rc = fail(DVN_ERR_DEVICE, "domain constant upload failed: %s", hipGetErrorString(e)); }
     } while (0);
     if (scratch) (void)hipFree(scratch);
@@ -121,9 +127,9 @@ template <class S> static int32_t ntt_device(dvn_ctx* ctx, const dvn_domain* d, 
         const u32 K = sb - sa;
         u32 log_i = 3;
         while (K + log_i > log_n) --log_i;                 // tile must not exceed the array
-        while (K + log_i > 11) --log_i;                    // <= 2048 elements = 64 KiB of LDS
+        while (((size_t)1 << (K + log_i)) * S::EW * 4 > 65536) --log_i;      // tile <= 64 KiB of LDS (2048 8-word / 1024 12-word elements)
         const u32 tiles = (u32)(((size_t)1 << log_n) >> (K + log_i));
-        const size_t lds = ((size_t)1 << (K + log_i)) * 32;
+        const size_t lds = ((size_t)1 << (K + log_i)) * S::EW * 4;
         NttScale use = none;
         if (sc.mode && ((sc.when == 1 && p == 0) || (sc.when == 2 && p == npass - 1))) use = sc;
         k_ntt_pass<S><<<tiles, 512, lds, ctx->stream>>>(data, tw, log_n, sa, sb, decimation == DVN_DIT, log_i, use);
@@ -155,17 +161,18 @@ template <class S> static int32_t compute_h_api(dvn_ctx* ctx, const char* name, 
     std::lock_guard<std::mutex> lk(ctx->mu);
     const bool on_dev = flags & DVN_NTT_DATA_ON_DEVICE;
     const hipMemcpyKind in_kind = on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    TRY(ensure_ws(ctx, 3 * n * 32 + 1024));
-    u32* da = (u32*)ctx->ws; u32* db = da + n * 8; u32* dc = db + n * 8;
+    constexpr size_t EB = S::EW * 4;                               // bytes per element
+    TRY(ensure_ws(ctx, 3 * n * EB + 1024));
+    u32* da = (u32*)ctx->ws; u32* db = da + n * S::EW; u32* dc = db + n * S::EW;
     hipStream_t st = ctx->stream;
-    HIP_TRY(hipMemsetAsync(da, 0, 3 * n * 32, st));
-    HIP_TRY(hipMemcpyAsync(da, a, len * 32, in_kind, st));
-    HIP_TRY(hipMemcpyAsync(db, b, len * 32, in_kind, st));
-    HIP_TRY(hipMemcpyAsync(dc, c, len * 32, in_kind, st));
+    HIP_TRY(hipMemsetAsync(da, 0, 3 * n * EB, st));
+    HIP_TRY(hipMemcpyAsync(da, a, len * EB, in_kind, st));
+    HIP_TRY(hipMemcpyAsync(db, b, len * EB, in_kind, st));
+    HIP_TRY(hipMemcpyAsync(dc, c, len * EB, in_kind, st));
     HIP_TRY(hipEventRecord(ctx->ev[0], st));
     TRY(compute_h_device<S>(ctx, dom, da, db, dc));
     HIP_TRY(hipEventRecord(ctx->ev[1], st));
-    HIP_TRY(hipMemcpyAsync(h_out, da, n * 32, on_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_out, da, n * EB, on_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipEventElapsedTime(&ctx->last_ms[0], ctx->ev[0], ctx->ev[1]));
     ctx->last_ms[1] = ctx->last_ms[0];

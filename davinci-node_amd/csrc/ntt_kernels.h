@@ -19,24 +19,26 @@
 
 namespace dvn {
 
+// one element = S::EW words (8 for the 253..255-bit scalar fields, 12 for BW6-761's 377-bit one)
 template <class S> __device__ __forceinline__ Fe<S> ld_fr(const u32* __restrict__ p) {
-    uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 4);
-    u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    u32 w[S::EW];
+#pragma unroll
+    for (int i = 0; i < S::EW; i += 4) { const uint4 v = *reinterpret_cast<const uint4*>(p + i); w[i] = v.x; w[i + 1] = v.y; w[i + 2] = v.z; w[i + 3] = v.w; }
     return fe_unpack<S>(w);
 }
-// weak form -> canonical -> 8 words
+// weak form -> canonical -> EW words
 template <class S> __device__ __forceinline__ void st_fr(const Fe<S>& v, u32* __restrict__ p) {
-    u32 w[8];
+    u32 w[S::EW];
     fe_pack<S>(fe_canonical<S>(v), w);
-    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
-    *reinterpret_cast<uint4*>(p + 4) = make_uint4(w[4], w[5], w[6], w[7]);
+#pragma unroll
+    for (int i = 0; i < S::EW; i += 4) *reinterpret_cast<uint4*>(p + i) = make_uint4(w[i], w[i + 1], w[i + 2], w[i + 3]);
 }
 // LDS staging keeps weak form (no canonicalisation between stages)
 template <class S> __device__ __forceinline__ void st_fr_weak(const Fe<S>& v, u32* p) {
-    u32 w[8];
+    u32 w[S::EW];
     fe_pack<S>(v, w);
-    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
-    *reinterpret_cast<uint4*>(p + 4) = make_uint4(w[4], w[5], w[6], w[7]);
+#pragma unroll
+    for (int i = 0; i < S::EW; i += 4) *reinterpret_cast<uint4*>(p + i) = make_uint4(w[i], w[i + 1], w[i + 2], w[i + 3]);
 }
 
 // out[k] = base^(k) * first, k < count; thread handles `chunk` consecutive entries.  base/first internal form.
@@ -45,8 +47,8 @@ template <class S> __global__ void k_powers(u32* __restrict__ out, const u32* __
     size_t lo = t * chunk;
     if (lo >= count) return;
     size_t hi = lo + chunk < count ? lo + chunk : count;
-    Fe<S> base = ld_fr<S>(base_first), cur = fe_mul<S>(fe_pow_u64<S>(base, (u64)lo), ld_fr<S>(base_first + 8));
-    for (size_t k = lo; k < hi; ++k) { st_fr<S>(cur, out + k * 8); cur = fe_mul<S>(cur, base); }
+    Fe<S> base = ld_fr<S>(base_first), cur = fe_mul<S>(fe_pow_u64<S>(base, (u64)lo), ld_fr<S>(base_first + S::EW));
+    for (size_t k = lo; k < hi; ++k) { st_fr<S>(cur, out + k * S::EW); cur = fe_mul<S>(cur, base); }
 }
 
 struct NttScale {
@@ -61,8 +63,8 @@ struct NttScale {
 template <class S> __device__ __forceinline__ Fe<S> ntt_scale_factor(const NttScale& sc, u32 i, u32 log_n) {
     if (sc.mode == 1) return ld_fr<S>(sc.lo);
     const u32 e = sc.bitrev ? (__brev(i) >> (32 - log_n)) : i;
-    Fe<S> f = ld_fr<S>(sc.lo + (size_t)(e & ((1u << sc.lo_bits) - 1)) * 8);
-    if (log_n > sc.lo_bits) f = fe_mul<S>(f, ld_fr<S>(sc.hi + (size_t)(e >> sc.lo_bits) * 8));
+    Fe<S> f = ld_fr<S>(sc.lo + (size_t)(e & ((1u << sc.lo_bits) - 1)) * S::EW);
+    if (log_n > sc.lo_bits) f = fe_mul<S>(f, ld_fr<S>(sc.hi + (size_t)(e >> sc.lo_bits) * S::EW));
     return f;
 }
 
@@ -101,9 +103,9 @@ template <class S> __global__ __launch_bounds__(512) void k_ntt_pass(u32* __rest
     for (u32 le = threadIdx.x; le < E; le += blockDim.x) {
         const u32 q = le & (I - 1), D = le >> log_i, sp = sp0 + q;
         const u32 gi = ((sp >> Lb) << (Lb + K)) | (D << Lb) | (sp & inner_mask);
-        Fr v = ld_fr<S>(data + (size_t)gi * 8);
+        Fr v = ld_fr<S>(data + (size_t)gi * S::EW);
         if (sc.mode && sc.when == 1) v = fe_mul<C>(v, ntt_scale_factor<S>(sc, gi, log_n));
-        st_fr_weak<S>(v, lds + (size_t)le * 8);
+        st_fr_weak<S>(v, lds + (size_t)le * S::EW);
     }
     __syncthreads();
     // ---- radix-4 rounds: executed stages t and t + 1
@@ -113,25 +115,25 @@ template <class S> __global__ __launch_bounds__(512) void k_ntt_pass(u32* __rest
         const u32 dlo = dit ? t : (K - 2 - t);
         const u32 s_first = dit ? (sb - 1 - t) : (sa + t);           // first executed stage
         const u32 s_second = dit ? (s_first - 1) : (s_first + 1);
-        const u32* tab1 = tw + ((size_t)n - (n >> s_first)) * 8;
-        const u32* tab2 = tw + ((size_t)n - (n >> s_second)) * 8;
+        const u32* tab1 = tw + ((size_t)n - (n >> s_first)) * S::EW;
+        const u32* tab2 = tw + ((size_t)n - (n >> s_second)) * S::EW;
         for (u32 u = threadIdx.x; u < (E >> 2); u += blockDim.x) {
             const u32 q = u & (I - 1), dq = u >> log_i;
             const u32 low = dq & ((1u << dlo) - 1);
             const u32 Db = ((dq >> dlo) << (dlo + 2)) | low;
             const u32 inner = (sp0 + q) & inner_mask;
             // x[hi][lo]: hi = bit dlo+1 of D, lo = bit dlo
-            u32* p00 = lds + (size_t)((Db << log_i) | q) * 8;
-            u32* p01 = lds + (size_t)(((Db | (1u << dlo)) << log_i) | q) * 8;
-            u32* p10 = lds + (size_t)(((Db | (2u << dlo)) << log_i) | q) * 8;
-            u32* p11 = lds + (size_t)(((Db | (3u << dlo)) << log_i) | q) * 8;
+            u32* p00 = lds + (size_t)((Db << log_i) | q) * S::EW;
+            u32* p01 = lds + (size_t)(((Db | (1u << dlo)) << log_i) | q) * S::EW;
+            u32* p10 = lds + (size_t)(((Db | (2u << dlo)) << log_i) | q) * S::EW;
+            u32* p11 = lds + (size_t)(((Db | (3u << dlo)) << log_i) | q) * S::EW;
             const Fr x00 = ld_fr<S>(p00), x01 = ld_fr<S>(p01), x10 = ld_fr<S>(p10), x11 = ld_fr<S>(p11);
             if (!dit) {
                 // stage s pairs over the HIGH bit (distance 2 << dlo), twiddle depends on the low bit;
                 // stage s+1 pairs over the LOW bit, one twiddle for the whole unit
-                const Fr wa0 = ld_fr<S>(tab1 + (size_t)((low << Lb) | inner) * 8);
-                const Fr wa1 = ld_fr<S>(tab1 + (size_t)((((1u << dlo) | low) << Lb) | inner) * 8);
-                const Fr wb = ld_fr<S>(tab2 + (size_t)((low << Lb) | inner) * 8);
+                const Fr wa0 = ld_fr<S>(tab1 + (size_t)((low << Lb) | inner) * S::EW);
+                const Fr wa1 = ld_fr<S>(tab1 + (size_t)((((1u << dlo) | low) << Lb) | inner) * S::EW);
+                const Fr wb = ld_fr<S>(tab2 + (size_t)((low << Lb) | inner) * S::EW);
                 const Fr A0 = ntt_red<S>(fe_add_lazy<C>(x00, x10)), A1 = ntt_red<S>(fe_add_lazy<C>(x01, x11));
                 const Fr B0 = fe_mul<C>(fe_sub_lazy<C, 4>(x00, x10), wa0), B1 = fe_mul<C>(fe_sub_lazy<C, 4>(x01, x11), wa1);
                 st_fr_weak<S>(ntt_red<S>(fe_add_lazy<C>(A0, A1)), p00);
@@ -140,9 +142,9 @@ template <class S> __global__ __launch_bounds__(512) void k_ntt_pass(u32* __rest
                 st_fr_weak<S>(fe_mul<C>(fe_sub_lazy<C, 2>(B0, B1), wb), p11);
             } else {
                 // stage s1 pairs over the LOW bit, one twiddle; stage s1-1 pairs over the HIGH bit, twiddle depends on the low bit
-                const Fr w1 = ld_fr<S>(tab1 + (size_t)((low << Lb) | inner) * 8);
-                const Fr w20 = ld_fr<S>(tab2 + (size_t)((low << Lb) | inner) * 8);
-                const Fr w21 = ld_fr<S>(tab2 + (size_t)((((1u << dlo) | low) << Lb) | inner) * 8);
+                const Fr w1 = ld_fr<S>(tab1 + (size_t)((low << Lb) | inner) * S::EW);
+                const Fr w20 = ld_fr<S>(tab2 + (size_t)((low << Lb) | inner) * S::EW);
+                const Fr w21 = ld_fr<S>(tab2 + (size_t)((((1u << dlo) | low) << Lb) | inner) * S::EW);
                 const Fr t0 = fe_mul<C>(x01, w1), t1 = fe_mul<C>(x11, w1);
                 const Fr a00 = fe_add_lazy<C>(x00, t0), a01 = fe_sub_lazy<C, 2>(x00, t0);     // < 5.1p, < 6p
                 const Fr a10 = fe_add_lazy<C>(x10, t1), a11 = fe_sub_lazy<C, 2>(x10, t1);
@@ -160,15 +162,15 @@ template <class S> __global__ __launch_bounds__(512) void k_ntt_pass(u32* __rest
         const u32 s = dit ? (sb - 1 - t) : (sa + t);
         const u32 tl = s - sa;
         const u32 dshift = K - 1 - tl, dist = 1u << dshift;
-        const u32* table = tw + ((size_t)n - (n >> s)) * 8;
+        const u32* table = tw + ((size_t)n - (n >> s)) * S::EW;
         for (u32 u = threadIdx.x; u < (E >> 1); u += blockDim.x) {
             const u32 q = u & (I - 1), dp = u >> log_i;
             const u32 low = dp & (dist - 1);
             const u32 D0 = ((dp >> dshift) << (dshift + 1)) | low, D1 = D0 | dist;
             const u32 j = (low << Lb) | ((sp0 + q) & inner_mask);
-            const Fr w = ld_fr<S>(table + (size_t)j * 8);
-            u32* pa = lds + (size_t)((D0 << log_i) | q) * 8;
-            u32* pb = lds + (size_t)((D1 << log_i) | q) * 8;
+            const Fr w = ld_fr<S>(table + (size_t)j * S::EW);
+            u32* pa = lds + (size_t)((D0 << log_i) | q) * S::EW;
+            u32* pb = lds + (size_t)((D1 << log_i) | q) * S::EW;
             const Fr a = ld_fr<S>(pa), b = ld_fr<S>(pb);
             if (!dit) {
                 st_fr_weak<S>(ntt_red<S>(fe_add_lazy<C>(a, b)), pa);
@@ -185,9 +187,9 @@ template <class S> __global__ __launch_bounds__(512) void k_ntt_pass(u32* __rest
     for (u32 le = threadIdx.x; le < E; le += blockDim.x) {
         const u32 q = le & (I - 1), D = le >> log_i, sp = sp0 + q;
         const u32 gi = ((sp >> Lb) << (Lb + K)) | (D << Lb) | (sp & inner_mask);
-        Fr v = ld_fr<S>(lds + (size_t)le * 8);
-        if (sc.mode && sc.when == 2) st_fr<S>(fe_mul<C>(v, ntt_scale_factor<S>(sc, gi, log_n)), data + (size_t)gi * 8);
-        else st_fr4<S>(v, data + (size_t)gi * 8);
+        Fr v = ld_fr<S>(lds + (size_t)le * S::EW);
+        if (sc.mode && sc.when == 2) st_fr<S>(fe_mul<C>(v, ntt_scale_factor<S>(sc, gi, log_n)), data + (size_t)gi * S::EW);
+        else st_fr4<S>(v, data + (size_t)gi * S::EW);
     }
 }
 
@@ -197,10 +199,10 @@ template <class S> __global__ void k_h_pointwise(u32* __restrict__ a, const u32*
                               const u32* __restrict__ k1k2, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const Fe<S> k1 = ld_fr<S>(k1k2), k2 = ld_fr<S>(k1k2 + 8);
-    Fe<S> ab = fe_mul<S>(fe_mul<S>(ld_fr<S>(a + i * 8), ld_fr<S>(b + i * 8)), k1);
-    Fe<S> cd = fe_mul<S>(ld_fr<S>(c + i * 8), k2);
-    st_fr<S>(fe_sub<S>(ab, cd), a + i * 8);
+    const Fe<S> k1 = ld_fr<S>(k1k2), k2 = ld_fr<S>(k1k2 + S::EW);
+    Fe<S> ab = fe_mul<S>(fe_mul<S>(ld_fr<S>(a + i * S::EW), ld_fr<S>(b + i * S::EW)), k1);
+    Fe<S> cd = fe_mul<S>(ld_fr<S>(c + i * S::EW), k2);
+    st_fr<S>(fe_sub<S>(ab, cd), a + i * S::EW);
 }
 
 }  // namespace dvn

@@ -45,7 +45,7 @@ template <class S> static int32_t suite_ntt(dvn_ctx* ctx, const char* name, cons
     if (dom->suite != DomainConsts<S>::SUITE) return fail(DVN_ERR_INVALID_ARG, "domain is not a %s domain", name);
     if (decimation != DVN_DIF && decimation != DVN_DIT) return fail(DVN_ERR_INVALID_ARG, "decimation must be DVN_DIF or DVN_DIT");
     std::lock_guard<std::mutex> lk(ctx->mu);
-    const size_t bytes = ((size_t)1 << dom->log_n) * 32;
+    const size_t bytes = ((size_t)1 << dom->log_n) * S::EW * 4;
     u32* d_data;
     const bool on_dev = flags & DVN_NTT_DATA_ON_DEVICE;
     if (on_dev) d_data = (u32*)data;

@@ -258,8 +258,8 @@ int32_t dvn_bls12381_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint6
  * prover/prover_gpu.go:52-57).  G1 (y^2 = x^3 - 1) and G2
  * (y^2 = x^3 + 4) both live over the 761-bit base field, so one entry point serves both; `group` (1 or 2) is recorded in
  * the handle.  gnark images: fp.Element 12 x uint64 (R = 2^768), G1Affine/G2Affine 24 x uint64, G1Jac/G2Jac 36 x uint64;
- * scalars are fr.Element = 6 x uint64 (R = 2^384; the field is BLS12-377's base field).  MSM only: the BW6-761 scalar
- * field's NTT (6-limb elements) is not instantiated yet. */
+ * scalars are fr.Element = 6 x uint64 (R = 2^384; the field is BLS12-377's base field), also the element type of the
+ * NTT (fft.Domain of ecc/bw6-761/fr: two-adicity 46, FrMultiplicativeGen 15) and of computeH. */
 int32_t dvn_bw6761_points_upload(dvn_ctx* ctx, int group, const uint64_t* xy_mont /* n x 24 */, size_t n, dvn_points** out);
 /* P_i = [s0]B + i*[s1]B from one caller-supplied affine point B (bench/test input generator) */
 int32_t dvn_bw6761_points_synthetic(dvn_ctx* ctx, int group, const uint64_t base_xy_mont[24], uint64_t seed, size_t n,
@@ -268,6 +268,12 @@ int32_t dvn_bw6761_points_download(dvn_ctx* ctx, const dvn_points* pts, size_t o
 int32_t dvn_bw6761_scalars_synthetic(dvn_ctx* ctx, uint64_t seed, int kind, size_t n, void* d_out /* n x 48 bytes */);
 int32_t dvn_bw6761_msm(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars_mont /* n x 6 */,
                        uint32_t flags, uint64_t out_jac[36]);
+
+int32_t dvn_bw6761_ntt_domain(dvn_ctx* ctx, uint32_t log_n, dvn_domain** out);                 /* log_n <= 27 */
+int32_t dvn_bw6761_ntt(dvn_ctx* ctx, const dvn_domain* dom, uint64_t* data /* n x 6 */, int inverse, int decimation, int on_coset,
+                       uint32_t flags);
+int32_t dvn_bw6761_groth16_compute_h(dvn_ctx* ctx, const dvn_domain* dom, const uint64_t* a, const uint64_t* b, const uint64_t* c,
+                                     size_t len, uint64_t* h_out /* n x 6 */, uint32_t flags);
 
 /* ---- timing of the last call's kernels, measured with HIP events on the library's own stream ---------- */
 /* which: 0 = whole device section of the last MSM/NTT call, 1 = its dominant kernel (MSM: bucket

@@ -357,6 +357,13 @@ class Bw6761:
         if sel < 90: return b.splitmix_at(seed, 6 * i)
         return self.fr_at(seed, i)
 
+    # scalar-field NTT (gnark-crypto ecc/bw6-761/fr/fft): GenericDomain only needs r, root, two_adicity, fr_gen
+    two_adicity, fr_gen = 46, 15
+    root = pow(15, (_P377 - 1) >> 46, _P377)
+
+    def domain(self, m):
+        return GenericDomain(self, m)
+
     def progression(self, base, seed, n):
         """P_i = [s0]B + i*[s1]B, (s0, s1) = the first two raw 256-bit blocks of stream `seed`
         (dvn_bw6761_points_synthetic)."""

@@ -161,3 +161,57 @@ def test_bw6761_msm_closed_form(bw6, ctx, W, log_n):
         assert list(got) == W.to_limbs(want), kind
         ctx.free(ds)
     dp.free()
+
+
+def test_bw6761_scalar_domain_constants(W, opy):
+    assert (W.r - 1) % (1 << 46) == 0 and (W.r - 1) % (1 << 47) != 0
+    assert pow(15, (W.r - 1) // 2, W.r) == W.r - 1                               # 15 is a non-residue: it can generate
+    assert W.root == 32863578547254505029601261939868325669770508939375122462904745766352256812585773382134936404344547323199885654433   # gnark-crypto fr/fft
+    assert pow(W.root, 1 << 45, W.r) == W.r - 1
+    d = W.domain(8); a = [W.fr_at(7, i) for i in range(8)]
+    ref = [sum(a[j] * pow(d.gen, i * j, W.r) for j in range(8)) % W.r for i in range(8)]
+    x = list(a); d.fft(x, opy.DIF)
+    assert [x[opy.bitrev(i, 3)] for i in range(8)] == ref
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n", [1, 2, 3, 5, 8, 9, 10])
+def test_bw6761_ntt_all_modes_vs_oracle(bw6, W, opy, log_n):
+    n = 1 << log_n
+    dom = bw6.domain(log_n)
+    d = W.domain(n)
+    x = [W.fr_at(2, i) for i in range(n)]
+    xm = np.array([W.fr_to_limbs(v) for v in x], dtype=np.uint64)
+    for inv in (False, True):
+        for dec in (0, 1):
+            for cos in (False, True):
+                y = list(x); (d.fft_inverse if inv else d.fft)(y, dec, cos)
+                ym = xm.copy(); bw6.ntt(dom, ym, inv, dec, cos)
+                assert [W.fr_from_limbs(r) for r in ym] == y, (log_n, inv, dec, cos)
+    dom.free()
+
+
+@pytest.mark.gpu
+def test_bw6761_ntt_large_roundtrip_and_compute_h(bw6, ctx, W, pkg):
+    log_n = 18
+    n = 1 << log_n
+    dom = bw6.domain(log_n)
+    dx = bw6.synthetic_scalars(2, 0, n)
+    x = np.empty((n, 6), dtype=np.uint64); ctx.d2h(x, dx)
+    y = np.empty_like(x)
+    for cos in (False, True):
+        bw6.ntt(dom, dx, False, pkg.DIF, cos); bw6.ntt(dom, dx, True, pkg.DIT, cos)
+        ctx.d2h(y, dx); assert (y == x).all()
+        bw6.ntt(dom, dx, True, pkg.DIF, cos); bw6.ntt(dom, dx, False, pkg.DIT, cos)
+        ctx.d2h(y, dx); assert (y == x).all()
+    ctx.free(dx); dom.free()
+    # computeH (ragged inputs) against the suite-generic oracle
+    for lg, ln in ((3, 8), (6, 50), (9, 512)):
+        dom = bw6.domain(lg); d = W.domain(1 << lg)
+        a, b, c = ([W.fr_at(s, i) for i in range(ln)] for s in (11, 12, 13))
+        L = lambda v: np.array([W.fr_to_limbs(t) for t in v], dtype=np.uint64)
+        got = bw6.compute_h(dom, L(a), L(b), L(c))
+        assert [W.fr_from_limbs(r) for r in got] == d.compute_h(a, b, c)
+        dom.free()
+    with pytest.raises(pkg.DvnError):
+        ctx.ntt(bw6.domain(4), np.zeros((16, 4), dtype=np.uint64), False, 0)     # BN254 entry on a BW6-761 domain
