@@ -125,6 +125,9 @@ def load_library():
         "dvn_bw6761_ntt_domain": (i32, [vp, u32, C.POINTER(vp)]),
         "dvn_bw6761_ntt": (i32, [vp, vp, vp, C.c_int, C.c_int, C.c_int, u32]),
         "dvn_bw6761_groth16_compute_h": (i32, [vp, vp, vp, vp, vp, sz, vp, u32]),
+        "dvn_bw6761_r1cs_synthetic": (i32, [u64, u32, u32, C.POINTER(vp)]),
+        "dvn_bw6761_groth16_setup": (i32, [vp, vp, u64, C.POINTER(vp)]),
+        "dvn_bw6761_groth16_prove": (i32, [vp, vp, vp, u32, vp, vp, vp]),
         "dvn_prover_use_gpu": (i32, []),
         "dvn_prover_set_use_gpu": (None, [i32]),
         "dvn_prover_reload_env": (None, []),
@@ -158,6 +161,7 @@ EXPORTED_SYMBOLS = [
     "dvn_bls12381_r1cs_synthetic", "dvn_bls12381_groth16_setup", "dvn_bls12381_groth16_prove", "dvn_r1cs_curve",
     "dvn_bw6761_points_upload", "dvn_bw6761_points_synthetic", "dvn_bw6761_points_download", "dvn_bw6761_scalars_synthetic", "dvn_bw6761_msm",
     "dvn_bw6761_ntt_domain", "dvn_bw6761_ntt", "dvn_bw6761_groth16_compute_h",
+    "dvn_bw6761_r1cs_synthetic", "dvn_bw6761_groth16_setup", "dvn_bw6761_groth16_prove",
     "dvn_prover_use_gpu", "dvn_prover_set_use_gpu", "dvn_prover_reload_env", "dvn_prover_set_prover", "dvn_prover_set_cpu_backend",
     "dvn_prover_last_backend", "dvn_prover_prove", "dvn_prover_setup",
 ]
@@ -400,7 +404,7 @@ class R1CS:
         self.n_wires, self.n_public, self.n_constraints = a.value, b.value, c.value
 
     def witness(self) -> np.ndarray:
-        out = np.zeros((self.n_wires, 4), dtype=np.uint64)
+        out = np.zeros((self.n_wires, 6 if self.curve == "bw6761" else 4), dtype=np.uint64)
         self.L.dvn_r1cs_witness(self.h, _host(out))
         return out
 
@@ -417,7 +421,8 @@ class Groth16Key:
         self.ctx = ctx
         self.curve = cs.curve
         self._prefix = "dvn_" if cs.curve == "bn254" else f"dvn_{cs.curve}_"
-        self._a1 = 8 if cs.curve == "bn254" else 12           # uint64 words of a G1Affine image (G2Affine: twice that)
+        self._a1 = {"bn254": 8, "bw6761": 24}.get(cs.curve, 12)      # uint64 words of a G1Affine image
+        self._a2 = self._a1 if cs.curve == "bw6761" else 2 * self._a1  # G2Affine: twice that, except BW6-761 (G2 over Fp)
         h = C.c_void_p()
         ctx._chk(getattr(ctx.L, self._prefix + "groth16_setup")(ctx.h, cs.h, seed, C.byref(h)))
         self.h = h
@@ -428,15 +433,15 @@ class Groth16Key:
 
     def prove(self, witness, r_mont: np.ndarray, s_mont: np.ndarray) -> dict:
         """witness: (m,4) uint64 host array or int device pointer.  Returns {'Ar': (8,), 'Bs': (16,), 'Krs': (8,)}."""
-        a1 = self._a1
-        out = np.zeros(4 * a1, dtype=np.uint64)
+        a1, a2 = self._a1, self._a2
+        out = np.zeros(2 * a1 + a2, dtype=np.uint64)
         r_mont = np.ascontiguousarray(r_mont, dtype=np.uint64); s_mont = np.ascontiguousarray(s_mont, dtype=np.uint64)
         if isinstance(witness, (int, np.integer)):
             wp, fl = C.c_void_p(int(witness)), 1
         else:
             witness = np.ascontiguousarray(witness, dtype=np.uint64); wp, fl = _host(witness), 0
         self.ctx._chk(getattr(self.ctx.L, self._prefix + "groth16_prove")(self.ctx.h, self.h, wp, fl, _host(r_mont), _host(s_mont), _host(out)))
-        return {"Ar": out[0:a1].copy(), "Bs": out[a1:3 * a1].copy(), "Krs": out[3 * a1:4 * a1].copy()}
+        return {"Ar": out[0:a1].copy(), "Bs": out[a1:a1 + a2].copy(), "Krs": out[a1 + a2:2 * a1 + a2].copy()}
 
     def last_ms(self):
         a, b, c = C.c_float(), C.c_float(), C.c_float()

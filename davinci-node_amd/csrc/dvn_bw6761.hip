@@ -7,6 +7,7 @@
 // (Ops<Fe<C>>::CALL_MUL) and the lazily reduced accumulator formulas are off (three products per column would
 // overflow 64 bits).
 #include "suite_api.h"
+#include "groth16_impl.h"
 
 static int32_t check_group(int group) { return (group == 1 || group == 2) ? DVN_OK : fail(DVN_ERR_INVALID_ARG, "group must be 1 (G1) or 2 (G2)"); }
 
@@ -63,4 +64,56 @@ extern "C" int32_t dvn_bw6761_ntt(dvn_ctx* ctx, const dvn_domain* dom, uint64_t*
 extern "C" int32_t dvn_bw6761_groth16_compute_h(dvn_ctx* ctx, const dvn_domain* dom, const uint64_t* a, const uint64_t* b, const uint64_t* c,
                                                 size_t len, uint64_t* h_out, uint32_t flags) {
     return compute_h_api<Fp377Cfg>(ctx, "BW6-761", dom, a, b, c, len, h_out, flags);
+}
+
+// ---- Groth16 on BW6-761 (the aggregator proof, one per batch; reference dispatch prover/prover_gpu.go:52-57) ------------------
+// Generators of the r-torsion for the SYNTHETIC setup: [#E / r] * (smallest-x point) on y^2 = x^3 - 1 and on y^2 = x^3 + 4,
+// the group orders from the CM trace (oracle/curves_py.py Bw6761.g1_gen / g2_gen; tests/test_groth16_curves.py re-derives
+// them).  Not gnark's generators -- production keys arrive through dvn_bw6761_points_upload.
+static G_761::A bw6_g1_generator() {
+    static const u64 g[24] = {
+        0x851a1c1166ae2603ULL, 0xeea72e25492571beULL, 0xa6f20c75f7feab02ULL, 0xeeea8a1b066c47a4ULL, 0x6469c9e9402afc4fULL, 0x4cd9755dfe95e5baULL,
+        0x3a1be33544ef7b02ULL, 0x1e7fe0555536b119ULL, 0xfd947c7fee73da05ULL, 0xcffde31744f837a0ULL, 0xa7b583036935c864ULL, 0x009918c73dcc124aULL,
+        0xa3c13889f58ed694ULL, 0xee5cb8acda0ea650ULL, 0xcea7c1807dfc6e02ULL, 0xdc672db2da00df5dULL, 0xcde53070a22b574dULL, 0x4f3dc271f97fe60bULL,
+        0xd5a2d25bb5f4cc8cULL, 0xd68088f33580a980ULL, 0x760b0d826b393143ULL, 0xe54149ee3970878eULL, 0xc62f69887a0e0ed1ULL, 0x0030ceaa8cbab39dULL};
+    return G_761::affine_from_ext((const u32*)g);
+}
+static G_761::A bw6_g2_generator() {
+    static const u64 g[24] = {
+        0x7a0fd858704768c5ULL, 0x6c5be1b80c64008fULL, 0xe1b3fb4bb1ac5852ULL, 0x2203b091f0fc31ddULL, 0x2ebf37c25b1eef12ULL, 0x49a1fad2457203d9ULL,
+        0x162db0b97521fa5cULL, 0xa6a1485ad8b21680ULL, 0xf5d702e72eed36deULL, 0xbef2f058a748dc3dULL, 0xcd04921580de2d02ULL, 0x011facfed9fa57fcULL,
+        0xe09e2c209f095996ULL, 0x4d01106af3817932ULL, 0x492aba5ca1eb141aULL, 0x00746773a4274e9dULL, 0xa2dc76b92ff2c456ULL, 0xf966c58bd85998d4ULL,
+        0x70f7b232c5c972f6ULL, 0x8397f5dd1e347c05ULL, 0x4ecba5f3f2ade37fULL, 0x8d8ebfa5a0d9b076ULL, 0xab65924d7383d531ULL, 0x0012b9419bd0fd43ULL};
+    return G_761::affine_from_ext((const u32*)g);
+}
+static const u32 R761_W[12] = {0x00000001u, 0x8508c000u, 0x30000000u, 0x170b5d44u, 0xba094800u, 0x1ef3622fu, 0x00f5138fu, 0x1a22d9f3u, 0x6ca1493bu, 0xc63b05c0u, 0x17c510eau, 0x01ae3a46u};
+struct SuiteBw6761 {
+    typedef Fp377Cfg FrC;
+    typedef G_761 G1T;
+    typedef G_761 G2T;
+    typedef FastHost<G_761>::G H1;
+    typedef FastHost<G_761>::G H2;
+    static constexpr int SUITE = 2;
+    static const u32* r_words() { return R761_W; }
+    static G_761::A g1_gen() { return bw6_g1_generator(); }
+    static G_761::A g2_gen() { return bw6_g2_generator(); }
+    static int32_t domain_create(dvn_ctx* ctx, u32 log_n, dvn_domain** out) { return ntt_domain_create<Fp377Cfg>(ctx, log_n, out); }
+    static int32_t compute_h(dvn_ctx* ctx, const dvn_domain* dom, u32* a, u32* b, u32* c) { return compute_h_device<Fp377Cfg>(ctx, dom, a, b, c); }
+    static int32_t msm_submit_g1(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, MsmLane** l) {
+        return msm_submit<G_761>(ctx, p, off, n, (const uint64_t*)s, DVN_MSM_SCALARS_ON_DEVICE, l);
+    }
+    static int32_t msm_submit_g2(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, MsmLane** l) { return msm_submit_g1(ctx, p, off, n, s, l); }
+    static int32_t msm_collect_g1(dvn_ctx* ctx, MsmLane* l, H1::X* out) { return msm_collect<G_761>(ctx, *l, out); }
+    static int32_t msm_collect_g2(dvn_ctx* ctx, MsmLane* l, H2::X* out) { return msm_collect<G_761>(ctx, *l, out); }
+};
+extern "C" int32_t dvn_bw6761_r1cs_synthetic(uint64_t seed, uint32_t n_constraints, uint32_t n_public, dvn_r1cs** out) {
+    return r1cs_synthetic<SuiteBw6761>(seed, n_constraints, n_public, out);
+}
+extern "C" int32_t dvn_bw6761_groth16_setup(dvn_ctx* ctx, const dvn_r1cs* cs, uint64_t seed, dvn_groth16_pk** out) {
+    return groth16_setup<SuiteBw6761>(ctx, cs, seed, out);
+}
+// witness: m x 6 uint64; r_mont / s_mont: 6 uint64 each; proof_out: Ar (24) | Bs (24) | Krs (24) uint64
+extern "C" int32_t dvn_bw6761_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
+                                            const uint64_t r_mont[6], const uint64_t s_mont[6], uint64_t proof_out[72]) {
+    return groth16_prove<SuiteBw6761>(ctx, pk, witness, flags, r_mont, s_mont, proof_out);
 }

@@ -32,8 +32,8 @@ extern "C" int32_t dvn_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uin
 }
 
 // ---- curve-independent handles ------------------------------------------------------------------------------------
-// gnark's ecc.ID numbering of the prover package mirror: 1 BN254, 2 BLS12_377, 3 BLS12_381
-extern "C" int32_t dvn_r1cs_curve(const dvn_r1cs* cs) { return !cs ? 0 : cs->suite == 0 ? 1 : cs->suite == 1 ? 2 : cs->suite == 3 ? 3 : 0; }
+// gnark's ecc.ID numbering of the prover package mirror: 1 BN254, 2 BLS12_377, 3 BLS12_381, 4 BW6_761
+extern "C" int32_t dvn_r1cs_curve(const dvn_r1cs* cs) { return !cs ? 0 : cs->suite == 0 ? 1 : cs->suite == 1 ? 2 : cs->suite == 3 ? 3 : cs->suite == 2 ? 4 : 0; }
 extern "C" int32_t dvn_r1cs_info(const dvn_r1cs* cs, uint32_t* n_wires, uint32_t* n_public, uint32_t* n_constraints) {
     if (!cs) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (n_wires) *n_wires = cs->n_wires;

@@ -7,7 +7,7 @@
 //   prover/prover_gpu.go:71  defaultProver           prover::defaultProver    GPU, on ANY error print + CPU fallback
 //   prover/prover_gpu.go:87  CPUProver(+WithWitness) prover::CPUProver        -> the registered CPU backend (gnark in production)
 //   prover/prover_gpu.go:99  GPUProver(+WithWitness) prover::GPUProver        -> callGPUProver: per-curve dispatch
-//   prover/prover_gpu.go:24  callGPUProver           prover::callGPUProver    BN254, BLS12_377, BLS12_381; BW6_761: "GPU proving not supported for curve"
+//   prover/prover_gpu.go:24  callGPUProver           prover::callGPUProver    all four curves of the reference; anything else: "GPU proving not supported for curve"
 //   prover/setup.go:15       Setup                   prover::Setup            -> dvn_groth16_setup, timing log
 // The CPU prover is NOT part of this library: in the node it is gnark's groth16.Prove.  CPUProver therefore calls a
 // backend registered by the embedder (dvn_prover_set_cpu_backend); with none registered it returns an error -- it never
@@ -56,7 +56,10 @@ int32_t callGPUProver(const Request* q) {
         case BLS12_381:
             if (!q->pk) return fail(DVN_ERR_INVALID_ARG, "proving key type mismatch for BLS12_381: expected a device-resident dvn_groth16_pk, got NULL");
             return dvn_bls12381_groth16_prove(q->ctx, q->pk, q->witness, 0, q->r, q->s, q->proof);
-        default:                 // BW6_761: MSM only so far (no scalar-field NTT) -> the caller falls back to the CPU prover
+        case BW6_761:
+            if (!q->pk) return fail(DVN_ERR_INVALID_ARG, "proving key type mismatch for BW6_761: expected a device-resident dvn_groth16_pk, got NULL");
+            return dvn_bw6761_groth16_prove(q->ctx, q->pk, q->witness, 0, q->r, q->s, q->proof);
+        default:
             return fail(DVN_ERR_UNSUPPORTED, "GPU proving not supported for curve %s", curve_name(q->curve));
     }
 }
@@ -90,7 +93,7 @@ int32_t Setup(dvn_ctx* ctx, const dvn_r1cs* ccs, uint64_t seed, dvn_groth16_pk**
     auto t0 = std::chrono::steady_clock::now();
     const int32_t cid = dvn_r1cs_curve(ccs);
     int32_t rc = cid == BLS12_377 ? dvn_bls12377_groth16_setup(ctx, ccs, seed, pk) : cid == BLS12_381 ? dvn_bls12381_groth16_setup(ctx, ccs, seed, pk)
-                                    : dvn_groth16_setup(ctx, ccs, seed, pk);
+               : cid == BW6_761 ? dvn_bw6761_groth16_setup(ctx, ccs, seed, pk) : dvn_groth16_setup(ctx, ccs, seed, pk);
     if (rc == DVN_OK) {
         double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         fprintf(stderr, "[prover] circuit keys setup done took=%.3fs gpu=%s constraints=%u\n", s, UseGPUProver ? "true" : "false", nc);

@@ -22,6 +22,11 @@
 #include "ntt_driver.h"
 #include "msm_driver.h"
 
+// k = canonical scalar, S::EW words: 64-bit-limb host arithmetic takes 8, the generic one any width
+template <class H, class S> static typename H::X host_mul(const typename H::X& p, const u32* k) {
+    if constexpr (S::EW == 8) return H::mul_scalar(p, k);
+    else return H::mul_scalar_n(p, k, S::EW);
+}
 template <class SU> struct HostKey { typename SU::H1::X alpha, beta, delta; typename SU::H2::X beta2, delta2; };
 
 // ------------------------------------------------------------------------------------------------------
@@ -64,24 +69,25 @@ template <class S> __global__ void k_r1cs_matvec(const u32* __restrict__ ptr, co
     if (r >= rows) return;
     Fe<S> acc = fe_zero<S>();
     for (u32 k = ptr[r]; k < ptr[r + 1]; ++k)
-        acc = fe_add<S>(acc, fe_mul<S>(ld_fr<S>(coef + (size_t)k * 8), ld_fr<S>(w + (size_t)idx[k] * 8)));
-    st_fr<S>(acc, out + (size_t)r * 8);
+        acc = fe_add<S>(acc, fe_mul<S>(ld_fr<S>(coef + (size_t)k * S::EW), ld_fr<S>(w + (size_t)idx[k] * S::EW)));
+    st_fr<S>(acc, out + (size_t)r * S::EW);
 }
-static __global__ void k_gather_fr(const u32* __restrict__ src, const u32* __restrict__ idx, u32* __restrict__ dst, size_t count) {
+template <int EW> __global__ void k_gather_fr(const u32* __restrict__ src, const u32* __restrict__ idx, u32* __restrict__ dst, size_t count) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    const uint4* s = reinterpret_cast<const uint4*>(src + (size_t)idx[i] * 8);
-    uint4* d = reinterpret_cast<uint4*>(dst + i * 8);
-    d[0] = s[0]; d[1] = s[1];
+    const uint4* s = reinterpret_cast<const uint4*>(src + (size_t)idx[i] * EW);
+    uint4* d = reinterpret_cast<uint4*>(dst + i * EW);
+#pragma unroll
+    for (int k = 0; k < EW / 4; ++k) d[k] = s[k];
 }
 // L_j(tau) = (tau^n - 1)/n * w^j / (tau - w^j); consts = {w, tau, (tau^n - 1)/n}, all internal form
 template <class S> __global__ void k_lagrange(u32* __restrict__ out, const u32* __restrict__ consts, size_t n) {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    const Fe<S> w = ld_fr<S>(consts), tau = ld_fr<S>(consts + 8), zn = ld_fr<S>(consts + 16);
+    const Fe<S> w = ld_fr<S>(consts), tau = ld_fr<S>(consts + S::EW), zn = ld_fr<S>(consts + 2 * S::EW);
     const Fe<S> wj = fe_pow_u64<S>(w, (u64)j);
     const Fe<S> den = fe_inv<S>(fe_sub<S>(tau, wj));
-    st_fr<S>(fe_mul<S>(fe_mul<S>(zn, wj), den), out + j * 8);
+    st_fr<S>(fe_mul<S>(fe_mul<S>(zn, wj), den), out + j * S::EW);
 }
 // column evaluation: out[i] = sum_k coef[k] * L[row[k]] over the entries of wire i (CSC of one R1CS matrix)
 template <class S> __global__ void k_col_eval(const u32* __restrict__ ptr, const u32* __restrict__ row, const u32* __restrict__ coef,
@@ -90,8 +96,8 @@ template <class S> __global__ void k_col_eval(const u32* __restrict__ ptr, const
     if (i >= cols) return;
     Fe<S> acc = fe_zero<S>();
     for (u32 k = ptr[i]; k < ptr[i + 1]; ++k)
-        acc = fe_add<S>(acc, fe_mul<S>(ld_fr<S>(coef + (size_t)k * 8), ld_fr<S>(L + (size_t)row[k] * 8)));
-    st_fr<S>(acc, out + (size_t)i * 8);
+        acc = fe_add<S>(acc, fe_mul<S>(ld_fr<S>(coef + (size_t)k * S::EW), ld_fr<S>(L + (size_t)row[k] * S::EW)));
+    st_fr<S>(acc, out + (size_t)i * S::EW);
 }
 // K_i = (beta * At_i + alpha * Bt_i + Ct_i) / delta for i >= n_public; consts = {alpha, beta, 1/delta}
 template <class S> __global__ void k_key_k(const u32* __restrict__ at, const u32* __restrict__ bt, const u32* __restrict__ ct,
@@ -99,22 +105,22 @@ template <class S> __global__ void k_key_k(const u32* __restrict__ at, const u32
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
     const size_t i = (size_t)first + t;
-    const Fe<S> alpha = ld_fr<S>(consts), beta = ld_fr<S>(consts + 8), dinv = ld_fr<S>(consts + 16);
-    Fe<S> v = fe_add<S>(fe_add<S>(fe_mul<S>(beta, ld_fr<S>(at + i * 8)), fe_mul<S>(alpha, ld_fr<S>(bt + i * 8))), ld_fr<S>(ct + i * 8));
-    st_fr<S>(fe_mul<S>(v, dinv), out + (size_t)t * 8);
+    const Fe<S> alpha = ld_fr<S>(consts), beta = ld_fr<S>(consts + S::EW), dinv = ld_fr<S>(consts + 2 * S::EW);
+    Fe<S> v = fe_add<S>(fe_add<S>(fe_mul<S>(beta, ld_fr<S>(at + i * S::EW)), fe_mul<S>(alpha, ld_fr<S>(bt + i * S::EW))), ld_fr<S>(ct + i * S::EW));
+    st_fr<S>(fe_mul<S>(v, dinv), out + (size_t)t * S::EW);
 }
 // Z'_i = zdt * tau^(bitrev(i)): gnark computes Z_i = (tau^n - 1)/delta * tau^i and bit-reverses the POINT array
 template <class S> __global__ void k_key_z(u32* __restrict__ out, const u32* __restrict__ consts /* {tau, zdt} */, u32 log_n) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (1u << log_n)) return;
-    const Fe<S> tau = ld_fr<S>(consts), zdt = ld_fr<S>(consts + 8);
+    const Fe<S> tau = ld_fr<S>(consts), zdt = ld_fr<S>(consts + S::EW);
     const u32 e = __brev(i) >> (32 - log_n);
-    st_fr<S>(fe_mul<S>(zdt, fe_pow_u64<S>(tau, (u64)e)), out + (size_t)i * 8);
+    st_fr<S>(fe_mul<S>(zdt, fe_pow_u64<S>(tau, (u64)e)), out + (size_t)i * S::EW);
 }
-// fixed-base table: table[(w * 256 + d)] = d * 2^(8w) * G (affine internal), d in 1..255, w in 0..31
-template <class Cv> __global__ void k_fb_table(u32* __restrict__ table, const u32* __restrict__ gen) {
+// fixed-base table: table[(w * 256 + d)] = d * 2^(8w) * G (affine internal), d in 1..255, w in 0..nwin-1 (nwin = scalar bytes)
+template <class Cv> __global__ void k_fb_table(u32* __restrict__ table, const u32* __restrict__ gen, u32 nwin) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 32 * 256) return;
+    if (t >= nwin * 256) return;
     const u32 w = t >> 8, d = t & 255;
     typename Cv::X p = Cv::from_affine(ld_affine<Cv>(gen));
     for (u32 k = 0; k < 8 * w; ++k) p = Cv::dbl(p);
@@ -128,10 +134,10 @@ template <class Cv, class S> __global__ void k_fixed_base(const u32* __restrict_
                                                  u32* __restrict__ out, size_t count) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    u32 kw[8];
-    fe_pack<S>(fe_canonical<S>(fe_mul<S>(ld_fr<S>(scalars + i * 8), fe_small<S>(1))), kw);   // internal -> integer
+    u32 kw[S::EW];
+    fe_pack<S>(fe_canonical<S>(fe_mul<S>(ld_fr<S>(scalars + i * S::EW), fe_small<S>(1))), kw);   // internal -> integer
     typename Cv::X acc = Cv::infinity();
-    for (u32 w = 0; w < 32; ++w) {
+    for (u32 w = 0; w < 4 * S::EW; ++w) {
         const u32 d = (kw[w >> 2] >> (8 * (w & 3))) & 255;
         if (d) acc = Cv::add_mixed(acc, ld_affine<Cv>(table + (size_t)(w * 256 + d) * Cv::AW));
     }
@@ -154,19 +160,22 @@ struct SplitMix {
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
         return z ^ (z >> 31);
     }
-    // canonical scalar as internal-form element: four stream words reduced mod r (oracle SplitMix64.next_fr)
-    template <class S> Fe<S> next_fr(const u32 rmod[8]) {
-        u32 w[8];
-        for (int k = 0; k < 4; ++k) { u64 v = next(); w[2 * k] = (u32)v; w[2 * k + 1] = (u32)(v >> 32); }
-        while (geq8(w, rmod)) sub8(w, rmod);
+    // canonical scalar as internal-form element: EW/2 stream words (the width of the field image) reduced mod r
+    // (oracle SplitMix64.next_fr / curves_py.SuiteRng)
+    template <class S> Fe<S> next_fr(const u32* rmod /* S::EW words */) {
+        constexpr int EW = S::EW;
+        u32 w[EW];
+        for (int k = 0; k < EW / 2; ++k) { u64 v = next(); w[2 * k] = (u32)v; w[2 * k + 1] = (u32)(v >> 32); }
+        auto geq = [&]() { for (int i = EW - 1; i >= 0; --i) { if (w[i] > rmod[i]) return true; if (w[i] < rmod[i]) return false; } return true; };
+        while (geq()) { u64 br = 0; for (int i = 0; i < EW; ++i) { u64 d = (u64)w[i] - rmod[i] - br; w[i] = (u32)d; br = (d >> 32) & 1; } }
         return fe_from_canonical<S>(fe_unpack<S>(w));
     }
 };
-template <class S> static Fe<S> fr_u64(u64 v) { u32 w[8] = {(u32)v, (u32)(v >> 32), 0, 0, 0, 0, 0, 0}; return fe_from_canonical<S>(fe_unpack<S>(w)); }
-template <class S> static void fr_pack_internal(const Fe<S>& v, u32* w) { u32 t[8]; fe_pack<S>(fe_canonical<S>(v), t); memcpy(w, t, 32); }
-template <class S> static void fr_to_ext_words(const Fe<S>& v, u32* w) { u32 t[8]; fe_to_ext_mont<S>(v, t); memcpy(w, t, 32); }
-template <class S> static void fr_canonical_words(const Fe<S>& v, u32* w) { u32 t[8]; fe_pack<S>(fe_canonical<S>(fe_mul<S>(v, fe_small<S>(1))), t); memcpy(w, t, 32); }
-template <class S> static Fe<S> fr_from_ext_words(const u64* p) { u32 t[8]; memcpy(t, p, 32); return fe_from_ext_mont<S>(t); }
+template <class S> static Fe<S> fr_u64(u64 v) { u32 w[S::EW] = {(u32)v, (u32)(v >> 32)}; return fe_from_canonical<S>(fe_unpack<S>(w)); }
+template <class S> static void fr_pack_internal(const Fe<S>& v, u32* w) { u32 t[S::EW]; fe_pack<S>(fe_canonical<S>(v), t); memcpy(w, t, S::EW * 4); }
+template <class S> static void fr_to_ext_words(const Fe<S>& v, u32* w) { u32 t[S::EW]; fe_to_ext_mont<S>(v, t); memcpy(w, t, S::EW * 4); }
+template <class S> static void fr_canonical_words(const Fe<S>& v, u32* w) { u32 t[S::EW]; fe_pack<S>(fe_canonical<S>(fe_mul<S>(v, fe_small<S>(1))), t); memcpy(w, t, S::EW * 4); }
+template <class S> static Fe<S> fr_from_ext_words(const u64* p) { u32 t[S::EW]; memcpy(t, p, S::EW * 4); return fe_from_ext_mont<S>(t); }
 
 template <class T> static int32_t dev_upload(T** d, const std::vector<T>& h) {
     HIP_TRY(hipMalloc((void**)d, h.size() * sizeof(T) + 16));
@@ -191,7 +200,7 @@ template <class SU> static int32_t r1cs_synthetic(uint64_t seed, uint32_t n_cons
     for (u32 i = 1; i < n_public; ++i) w.push_back(rng.template next_fr<S>(SU::r_words()));
     for (u32 i = 0; i < n_free; ++i) w.push_back(rng.template next_fr<S>(SU::r_words()));
     for (int k = 0; k < 3; ++k) cs->m[k].ptr.push_back(0);
-    auto push = [&](Csr& c, u32 wire, u64 coefv) { c.idx.push_back(wire); u32 t[8]; fr_pack_internal<S>(fr_u64<S>(coefv), t); c.coef.insert(c.coef.end(), t, t + 8); };
+    auto push = [&](Csr& c, u32 wire, u64 coefv) { c.idx.push_back(wire); u32 t[S::EW]; fr_pack_internal<S>(fr_u64<S>(coefv), t); c.coef.insert(c.coef.end(), t, t + S::EW); };
     for (u32 j = 0; j < n_constraints; ++j) {
         const u64 mcur = w.size();
         const u32 l1 = (u32)(rng.next() % mcur), l2 = (u32)(rng.next() % mcur);
@@ -205,8 +214,8 @@ template <class SU> static int32_t r1cs_synthetic(uint64_t seed, uint32_t n_cons
         for (int q = 0; q < 3; ++q) cs->m[q].ptr.push_back((u32)cs->m[q].idx.size());
     }
     cs->n_wires = (u32)w.size(); cs->n_public = n_public; cs->n_constraints = n_constraints;
-    cs->witness.resize((size_t)cs->n_wires * 8);
-    for (size_t i = 0; i < w.size(); ++i) fr_to_ext_words<S>(w[i], cs->witness.data() + i * 8);
+    cs->witness.resize((size_t)cs->n_wires * S::EW);
+    for (size_t i = 0; i < w.size(); ++i) fr_to_ext_words<S>(w[i], cs->witness.data() + i * S::EW);
     *out = cs;
     return DVN_OK;
 }
@@ -224,11 +233,11 @@ static int32_t fixed_base_points(dvn_ctx* ctx, const typename Cv::A& gen, const 
     u32 hg[Cv::AW];
     Cv::store_affine_internal(gen, hg);
     hipError_t e = hipMalloc((void**)&p->d, count ? count * Cv::AW * 4 * p->nexp : 16);
-    if (e == hipSuccess) e = hipMalloc((void**)&table, (size_t)32 * 256 * Cv::AW * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&table, (size_t)4 * S::EW * 256 * Cv::AW * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&dgen, sizeof(hg));
     if (e == hipSuccess) e = hipMemcpy(dgen, hg, sizeof(hg), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        k_fb_table<Cv><<<32 * 256 / 64, 64, 0, ctx->stream>>>(table, dgen);
+        k_fb_table<Cv><<<4 * S::EW * 256 / 64, 64, 0, ctx->stream>>>(table, dgen, 4 * S::EW);
         if (count) k_fixed_base<Cv, S><<<(unsigned)((count + 63) / 64), 64, 0, ctx->stream>>>(table, d_scalars, p->d, count);
         if (count && p->expand_c) k_points_expand<Cv><<<(unsigned)((count + 63) / 64), 64, 0, ctx->stream>>>(p->d, count, p->expand_c, p->nexp);
         e = hipGetLastError();
@@ -249,6 +258,8 @@ template <class SU> static int32_t groth16_setup(dvn_ctx* ctx, const dvn_r1cs* c
     typedef typename SU::G2T G2;
     typedef typename SU::H1 H1;
     typedef typename SU::H2 H2;
+    constexpr u32 EW = S::EW;                  // u32 words of a scalar image
+    constexpr size_t EB = (size_t)EW * 4;
     TRY(enter(ctx));
     if (!cs || !out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (cs->suite != SU::SUITE) return fail(DVN_ERR_INVALID_ARG, "constraint system belongs to another curve");
@@ -279,28 +290,28 @@ template <class SU> static int32_t groth16_setup(dvn_ctx* ctx, const dvn_r1cs* c
     };
     auto body = [&]() -> int32_t {
         hipStream_t st = ctx->stream;
-        HIP_TRY(hipMalloc((void**)&d_L, n * 32));
-        HIP_TRY(hipMalloc((void**)&d_consts, 8 * 32));
-        for (int q = 0; q < 3; ++q) HIP_TRY(hipMalloc((void**)&d_t[q], m * 32));
-        u32 hc[8 * 8];
-        fr_pack_internal<S>(omega, hc); fr_pack_internal<S>(tau, hc + 8);
-        fr_pack_internal<S>(fe_mul<S>(ztau, fe_inv<S>(fr_u64<S>(n))), hc + 16);
-        fr_pack_internal<S>(alpha, hc + 24); fr_pack_internal<S>(beta, hc + 32); fr_pack_internal<S>(dinv, hc + 40);
-        fr_pack_internal<S>(tau, hc + 48); fr_pack_internal<S>(fe_mul<S>(ztau, dinv), hc + 56);
+        HIP_TRY(hipMalloc((void**)&d_L, n * EB));
+        HIP_TRY(hipMalloc((void**)&d_consts, 8 * EB));
+        for (int q = 0; q < 3; ++q) HIP_TRY(hipMalloc((void**)&d_t[q], m * EB));
+        u32 hc[8 * EW];
+        fr_pack_internal<S>(omega, hc); fr_pack_internal<S>(tau, hc + EW);
+        fr_pack_internal<S>(fe_mul<S>(ztau, fe_inv<S>(fr_u64<S>(n))), hc + 2 * EW);
+        fr_pack_internal<S>(alpha, hc + 3 * EW); fr_pack_internal<S>(beta, hc + 4 * EW); fr_pack_internal<S>(dinv, hc + 5 * EW);
+        fr_pack_internal<S>(tau, hc + 6 * EW); fr_pack_internal<S>(fe_mul<S>(ztau, dinv), hc + 7 * EW);
         HIP_TRY(hipMemcpy(d_consts, hc, sizeof(hc), hipMemcpyHostToDevice));
         k_lagrange<S><<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_L, d_consts, n);
         HIP_TRY(hipGetLastError());
         // column (CSC) form of each matrix, evaluated at tau
         for (int q = 0; q < 3; ++q) {
             const Csr& r = cs->m[q];
-            std::vector<u32> cptr(m + 1, 0), crow(r.idx.size()), ccoef(r.idx.size() * 8);
+            std::vector<u32> cptr(m + 1, 0), crow(r.idx.size()), ccoef(r.idx.size() * EW);
             for (u32 wi : r.idx) cptr[wi + 1]++;
             for (size_t i = 0; i < m; ++i) cptr[i + 1] += cptr[i];
             std::vector<u32> cur(cptr.begin(), cptr.end() - 1);
             for (u32 row = 0; row < cs->n_constraints; ++row)
                 for (u32 k = r.ptr[row]; k < r.ptr[row + 1]; ++k) {
                     const u32 pos = cur[r.idx[k]]++;
-                    crow[pos] = row; memcpy(&ccoef[(size_t)pos * 8], &r.coef[(size_t)k * 8], 32);
+                    crow[pos] = row; memcpy(&ccoef[(size_t)pos * EW], &r.coef[(size_t)k * EW], EB);
                 }
             TRY(dev_upload(&d_cptr, cptr)); TRY(dev_upload(&d_crow, crow)); TRY(dev_upload(&d_ccoef, ccoef));
             k_col_eval<S><<<(unsigned)((m + 63) / 64), 64, 0, st>>>(d_cptr, d_crow, d_ccoef, d_L, d_t[q], (u32)m);
@@ -312,51 +323,51 @@ template <class SU> static int32_t groth16_setup(dvn_ctx* ctx, const dvn_r1cs* c
         }
         // K (private wires) and Z (bit-reversed)
         const size_t nk = m - cs->n_public;
-        HIP_TRY(hipMalloc((void**)&d_k, (nk ? nk : 1) * 32));
-        HIP_TRY(hipMalloc((void**)&d_z, n * 32));
-        if (nk) k_key_k<S><<<(unsigned)((nk + 63) / 64), 64, 0, st>>>(d_t[0], d_t[1], d_t[2], d_consts + 24, d_k, cs->n_public, (u32)nk);
-        k_key_z<S><<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_z, d_consts + 48, log_n);
+        HIP_TRY(hipMalloc((void**)&d_k, (nk ? nk : 1) * EB));
+        HIP_TRY(hipMalloc((void**)&d_z, n * EB));
+        if (nk) k_key_k<S><<<(unsigned)((nk + 63) / 64), 64, 0, st>>>(d_t[0], d_t[1], d_t[2], d_consts + 3 * EW, d_k, cs->n_public, (u32)nk);
+        k_key_z<S><<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_z, d_consts + 6 * EW, log_n);
         HIP_TRY(hipGetLastError());
         // infinity filtering of A and B (gnark's InfinityA / InfinityB)
-        std::vector<u32> hA(m * 8), hB(m * 8);
-        HIP_TRY(hipMemcpyAsync(hA.data(), d_t[0], m * 32, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(hB.data(), d_t[1], m * 32, hipMemcpyDeviceToHost, st));
+        std::vector<u32> hA(m * EW), hB(m * EW);
+        HIP_TRY(hipMemcpyAsync(hA.data(), d_t[0], m * EB, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(hB.data(), d_t[1], m * EB, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         std::vector<u32> idxA, idxB;
-        auto nonzero = [](const u32* p) { u32 z = 0; for (int k = 0; k < 8; ++k) z |= p[k]; return z != 0; };
-        for (u32 i = 0; i < m; ++i) { if (nonzero(&hA[(size_t)i * 8])) idxA.push_back(i); if (nonzero(&hB[(size_t)i * 8])) idxB.push_back(i); }
+        auto nonzero = [](const u32* p) { u32 z = 0; for (u32 k = 0; k < EW; ++k) z |= p[k]; return z != 0; };
+        for (u32 i = 0; i < m; ++i) { if (nonzero(&hA[(size_t)i * EW])) idxA.push_back(i); if (nonzero(&hB[(size_t)i * EW])) idxB.push_back(i); }
         pk->nA = idxA.size(); pk->nB = idxB.size();
         TRY(dev_upload(&pk->d_idxA, idxA)); TRY(dev_upload(&pk->d_idxB, idxB));
         const size_t cmax = std::max(pk->nA, pk->nB);
-        HIP_TRY(hipMalloc((void**)&d_cmp, (cmax ? cmax : 1) * 32));
+        HIP_TRY(hipMalloc((void**)&d_cmp, (cmax ? cmax : 1) * EB));
         const typename G1::A g1 = SU::g1_gen();
         const typename G2::A g2 = SU::g2_gen();
-        if (pk->nA) k_gather_fr<<<(unsigned)((pk->nA + 255) / 256), 256, 0, st>>>(d_t[0], pk->d_idxA, d_cmp, pk->nA);
+        if (pk->nA) k_gather_fr<S::EW><<<(unsigned)((pk->nA + 255) / 256), 256, 0, st>>>(d_t[0], pk->d_idxA, d_cmp, pk->nA);
         HIP_TRY(hipGetLastError());
         TRY((fixed_base_points<G1, S>(ctx, g1, d_cmp, pk->nA, 1, &pk->A)));
-        if (pk->nB) k_gather_fr<<<(unsigned)((pk->nB + 255) / 256), 256, 0, st>>>(d_t[1], pk->d_idxB, d_cmp, pk->nB);
+        if (pk->nB) k_gather_fr<S::EW><<<(unsigned)((pk->nB + 255) / 256), 256, 0, st>>>(d_t[1], pk->d_idxB, d_cmp, pk->nB);
         HIP_TRY(hipGetLastError());
         TRY((fixed_base_points<G1, S>(ctx, g1, d_cmp, pk->nB, 1, &pk->B)));
         TRY((fixed_base_points<G2, S>(ctx, g2, d_cmp, pk->nB, 2, &pk->B2)));
         TRY((fixed_base_points<G1, S>(ctx, g1, d_k, nk, 1, &pk->K)));
         TRY((fixed_base_points<G1, S>(ctx, g1, d_z, n, 1, &pk->Z)));
         // per-proof buffers
-        HIP_TRY(hipMalloc((void**)&pk->d_w, m * 32));
-        HIP_TRY(hipMalloc((void**)&pk->d_abc, 3 * n * 32));
-        HIP_TRY(hipMalloc((void**)&pk->d_wA, (pk->nA ? pk->nA : 1) * 32));
-        HIP_TRY(hipMalloc((void**)&pk->d_wB, (pk->nB ? pk->nB : 1) * 32));
+        HIP_TRY(hipMalloc((void**)&pk->d_w, m * EB));
+        HIP_TRY(hipMalloc((void**)&pk->d_abc, 3 * n * EB));
+        HIP_TRY(hipMalloc((void**)&pk->d_wA, (pk->nA ? pk->nA : 1) * EB));
+        HIP_TRY(hipMalloc((void**)&pk->d_wB, (pk->nB ? pk->nB : 1) * EB));
         // G1/G2 constants of the key
-        u32 kw[8], img1[G1::AW], img2[G2::AW];
+        u32 kw[EW], img1[G1::AW], img2[G2::AW];
         G1::store_affine_internal(g1, img1); G2::store_affine_internal(g2, img2);
         const typename H1::X hg1 = H1::load_device_affine(img1);
         const typename H2::X hg2 = H2::load_device_affine(img2);
         HostKey<SU>* hk = new HostKey<SU>();
         pk->hk = hk; pk->hk_free = [](void* p) { delete (HostKey<SU>*)p; };
-        fr_canonical_words<S>(alpha, kw); hk->alpha = H1::normalize(H1::mul_scalar(hg1, kw));
-        fr_canonical_words<S>(beta, kw); hk->beta = H1::normalize(H1::mul_scalar(hg1, kw));
-        hk->beta2 = H2::normalize(H2::mul_scalar(hg2, kw));
-        fr_canonical_words<S>(delta, kw); hk->delta = H1::normalize(H1::mul_scalar(hg1, kw));
-        hk->delta2 = H2::normalize(H2::mul_scalar(hg2, kw));
+        fr_canonical_words<S>(alpha, kw); hk->alpha = H1::normalize(host_mul<H1, S>(hg1, kw));
+        fr_canonical_words<S>(beta, kw); hk->beta = H1::normalize(host_mul<H1, S>(hg1, kw));
+        hk->beta2 = H2::normalize(host_mul<H2, S>(hg2, kw));
+        fr_canonical_words<S>(delta, kw); hk->delta = H1::normalize(host_mul<H1, S>(hg1, kw));
+        hk->delta2 = H2::normalize(host_mul<H2, S>(hg2, kw));
         return DVN_OK;
     };
     rc = body();
@@ -374,10 +385,12 @@ template <class SU> static int32_t groth16_setup(dvn_ctx* ctx, const dvn_r1cs* c
 // factors gnark draws from crypto/rand, injected so results are reproducible.  proof_out: Ar | Bs | Krs as affine
 // Montgomery images exactly as gnark's Proof holds them (G1Affine, G2Affine, G1Affine of the curve).
 template <class SU> static int32_t groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
-                                                 const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t* proof_out) {
+                                                 const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out) {
     typedef typename SU::FrC S;
     typedef typename SU::G1T G1;
     typedef typename SU::G2T G2;
+    constexpr u32 EW = S::EW;
+    constexpr size_t EB = (size_t)EW * 4;
     TRY(enter(ctx));
     if (!pk || !witness || !r_mont || !s_mont || !proof_out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (pk->suite != SU::SUITE) return fail(DVN_ERR_INVALID_ARG, "proving key belongs to another curve");
@@ -389,19 +402,19 @@ template <class SU> static int32_t groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* p
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
     auto body = [&]() -> int32_t {
         HIP_TRY(hipEventRecord(e0, st));
-        HIP_TRY(hipMemcpyAsync(pk->d_w, witness, m * 32, (flags & 1) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(pk->d_w, witness, m * EB, (flags & 1) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
         // (1) "solve": a = A w, b = B w, c = C w, zero padded to the domain size
-        HIP_TRY(hipMemsetAsync(pk->d_abc, 0, 3 * n * 32, st));
+        HIP_TRY(hipMemsetAsync(pk->d_abc, 0, 3 * n * EB, st));
         for (int q = 0; q < 3; ++q)
             k_r1cs_matvec<S><<<(unsigned)((pk->n_constraints + 127) / 128), 128, 0, st>>>(pk->d_ptr[q], pk->d_idx[q], pk->d_coef[q], pk->d_w,
-                                                                                      pk->d_abc + (size_t)q * n * 8, (u32)pk->n_constraints);
+                                                                                      pk->d_abc + (size_t)q * n * EW, (u32)pk->n_constraints);
         HIP_TRY(hipGetLastError());
         // (3) h = computeH(a, b, c), left on the device as the scalar vector of the Z MSM
-        TRY(SU::compute_h(ctx, pk->dom, pk->d_abc, pk->d_abc + n * 8, pk->d_abc + 2 * n * 8));
+        TRY(SU::compute_h(ctx, pk->dom, pk->d_abc, pk->d_abc + n * EW, pk->d_abc + 2 * n * EW));
         HIP_TRY(hipEventRecord(e1, st));
         // (4) filter the wire vector by InfinityA / InfinityB
-        if (pk->nA) k_gather_fr<<<(unsigned)((pk->nA + 255) / 256), 256, 0, st>>>(pk->d_w, pk->d_idxA, pk->d_wA, pk->nA);
-        if (pk->nB) k_gather_fr<<<(unsigned)((pk->nB + 255) / 256), 256, 0, st>>>(pk->d_w, pk->d_idxB, pk->d_wB, pk->nB);
+        if (pk->nA) k_gather_fr<S::EW><<<(unsigned)((pk->nA + 255) / 256), 256, 0, st>>>(pk->d_w, pk->d_idxA, pk->d_wA, pk->nA);
+        if (pk->nB) k_gather_fr<S::EW><<<(unsigned)((pk->nB + 255) / 256), 256, 0, st>>>(pk->d_w, pk->d_idxB, pk->d_wB, pk->nB);
         HIP_TRY(hipGetLastError());
         // (6) the five MSMs
         typedef typename SU::H1 H1;
@@ -415,7 +428,7 @@ template <class SU> static int32_t groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* p
         TRY(SU::msm_collect_g1(ctx, l1, &mA));
         TRY(SU::msm_submit_g1(ctx, pk->B, 0, pk->nB, pk->d_wB, &l1));
         TRY(SU::msm_collect_g1(ctx, l1, &mB));
-        TRY(SU::msm_submit_g1(ctx, pk->K, 0, m - pk->n_public, pk->d_w + pk->n_public * 8, &l1));
+        TRY(SU::msm_submit_g1(ctx, pk->K, 0, m - pk->n_public, pk->d_w + pk->n_public * EW, &l1));
         TRY(SU::msm_collect_g1(ctx, l1, &mK));
         TRY(SU::msm_submit_g1(ctx, pk->Z, 0, n - 1, pk->d_abc, &l1));               // h[:n-1] against Z[:n-1]
         TRY(SU::msm_collect_g1(ctx, l1, &mZ));
@@ -424,19 +437,19 @@ template <class SU> static int32_t groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* p
         HIP_TRY(hipStreamSynchronize(st));
         // (5)(7) blinding and assembly on the host: O(1) group operations (host_fast.h)
         const Fe<S> r = fr_from_ext_words<S>(r_mont), s = fr_from_ext_words<S>(s_mont);
-        u32 rw[8], sw[8], krw[8];
+        u32 rw[EW], sw[EW], krw[EW];
         fr_canonical_words<S>(r, rw); fr_canonical_words<S>(s, sw);
         fr_canonical_words<S>(fe_neg<S>(fe_mul<S>(r, s)), krw);
         // the six scalar multiplications are independent in two rounds: run them on host threads (on the curves without
         // 64-bit-limb host arithmetic one of them costs ~0.5 ms)
-        auto a_dr = std::async(std::launch::async, [&] { return H1::mul_scalar(hk.delta, rw); });
-        auto a_ds = std::async(std::launch::async, [&] { return H1::mul_scalar(hk.delta, sw); });
-        auto a_d2s = std::async(std::launch::async, [&] { return H2::mul_scalar(hk.delta2, sw); });
-        auto a_dk = std::async(std::launch::async, [&] { return H1::mul_scalar(hk.delta, krw); });
+        auto a_dr = std::async(std::launch::async, [&] { return host_mul<H1, S>(hk.delta, rw); });
+        auto a_ds = std::async(std::launch::async, [&] { return host_mul<H1, S>(hk.delta, sw); });
+        auto a_d2s = std::async(std::launch::async, [&] { return host_mul<H2, S>(hk.delta2, sw); });
+        auto a_dk = std::async(std::launch::async, [&] { return host_mul<H1, S>(hk.delta, krw); });
         const typename H1::X ar = H1::normalize(H1::add(H1::add(mA, hk.alpha), a_dr.get()));
         const typename H1::X bs1 = H1::normalize(H1::add(H1::add(mB, hk.beta), a_ds.get()));
-        auto a_ars = std::async(std::launch::async, [&] { return H1::mul_scalar(ar, sw); });
-        auto a_bsr = std::async(std::launch::async, [&] { return H1::mul_scalar(bs1, rw); });
+        auto a_ars = std::async(std::launch::async, [&] { return host_mul<H1, S>(ar, sw); });
+        auto a_bsr = std::async(std::launch::async, [&] { return host_mul<H1, S>(bs1, rw); });
         const typename H2::X bs = H2::add(H2::add(mB2, hk.beta2), a_d2s.get());
         typename H1::X krs = H1::add(mK, mZ);
         krs = H1::add(krs, a_dk.get());

@@ -495,9 +495,10 @@ template <class Cv> struct SlowHostG {
         typename Cv::A a = Cv::to_affine(p);
         O::to_ext(a.x, w); O::to_ext(a.y, w + FW); O::to_ext(O::one(), w + 2 * FW);
     }    // the O(1) finishing arithmetic of a proof (groth16_impl.h): k is a canonical 256-bit integer
-    static X mul_scalar(const X& p, const u32 k[8]) {
+    static X mul_scalar(const X& p, const u32 k[8]) { return mul_scalar_n(p, k, 8); }
+    static X mul_scalar_n(const X& p, const u32* k, u32 nwords) {
         X acc = Cv::infinity();
-        for (int b = 255; b >= 0; --b) {
+        for (int b = (int)nwords * 32 - 1; b >= 0; --b) {
             acc = Cv::dbl(acc);
             if ((k[b >> 5] >> (b & 31)) & 1) acc = Cv::add(acc, p);
         }

@@ -140,7 +140,7 @@ int32_t dvn_groth16_compute_h(dvn_ctx* ctx, const dvn_domain* dom, const uint64_
 typedef struct dvn_r1cs dvn_r1cs;
 typedef struct dvn_groth16_pk dvn_groth16_pk;
 int32_t dvn_r1cs_synthetic(uint64_t seed, uint32_t n_constraints, uint32_t n_public, dvn_r1cs** out);
-/* gnark ecc.ID of the system's curve as the prover mirror numbers them: 1 BN254, 2 BLS12_377, 3 BLS12_381 */
+/* gnark ecc.ID of the system's curve as the prover mirror numbers them: 1 BN254, 2 BLS12_377, 3 BLS12_381, 4 BW6_761 */
 int32_t dvn_r1cs_curve(const dvn_r1cs* cs);
 int32_t dvn_r1cs_info(const dvn_r1cs* cs, uint32_t* n_wires, uint32_t* n_public, uint32_t* n_constraints);
 int32_t dvn_r1cs_witness(const dvn_r1cs* cs, uint64_t* out /* n_wires x 4, Montgomery */);
@@ -274,6 +274,13 @@ int32_t dvn_bw6761_ntt(dvn_ctx* ctx, const dvn_domain* dom, uint64_t* data /* n 
                        uint32_t flags);
 int32_t dvn_bw6761_groth16_compute_h(dvn_ctx* ctx, const dvn_domain* dom, const uint64_t* a, const uint64_t* b, const uint64_t* c,
                                      size_t len, uint64_t* h_out /* n x 6 */, uint32_t flags);
+
+/* Groth16 on BW6-761 (the aggregator proof): Setup / Prove mirrors as for the other curves.  witness: m x 6 uint64,
+ * r_mont / s_mont: 6 uint64 each, proof_out: Ar (24) | Bs (24) | Krs (24) uint64 = gnark's groth16_bw6761.Proof images. */
+int32_t dvn_bw6761_r1cs_synthetic(uint64_t seed, uint32_t n_constraints, uint32_t n_public, dvn_r1cs** out);
+int32_t dvn_bw6761_groth16_setup(dvn_ctx* ctx, const dvn_r1cs* cs, uint64_t seed, dvn_groth16_pk** out);
+int32_t dvn_bw6761_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
+                                 const uint64_t r_mont[6], const uint64_t s_mont[6], uint64_t proof_out[72]);
 
 /* ---- timing of the last call's kernels, measured with HIP events on the library's own stream ---------- */
 /* which: 0 = whole device section of the last MSM/NTT call, 1 = its dominant kernel (MSM: bucket

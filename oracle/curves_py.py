@@ -357,6 +357,17 @@ class Bw6761:
         if sel < 90: return b.splitmix_at(seed, 6 * i)
         return self.fr_at(seed, i)
 
+    # r-torsion generators for the library's SYNTHETIC Groth16 setup: [#E/r] * some_point(group), orders from the CM trace
+    # (tests/test_groth16_curves.py re-derives them); the Suite-style aliases let the generic trapdoor oracle run on this curve
+    g1_gen = (0xd82cbf66753123ed25942ffadbec116b901330673728468b1653febae12aa13a5d68dc240a36cfbe185365abc6cb0cc5042c14be9179f0c6c05fc952c93a806d5316c2b601db66bd557011eb2c7dd0c1891418e3ce0e512da946c2ca98c56f,
+              0xa62fd67fdd91e327a96c02bc80385547a171b11241a2653b54d7359cd7569806b159fd05975390f644cd4d4d121918f1f84be0e364c557f196bd4095e732d987ca22009ba7577b80aaa35b641488679ed9ef0d43b32e776ad507137f20a2dd)
+    g2_gen = (0x4cd0ed4bbb4bad28e9646093e4c6ab32a3a80f35265437deef8f50aa1221f459b249d724b2c155e2bf40a492ead210323e3f1c3e6991b9bcabe9da05882daf12d84f49c477fd322fc532b59d18f40b4cc45de6fbd67847acac591e8c5a93fa,
+              0x5bbdc19380f7c707f6fe8680ef10cd46fa210a92bc4f56f1b92ab610ecb3fd508160dc51bab3ee5072aa3dedbe0766414556817439a0fbc33df16a239fc281edec5df53182dcf168c9171615a79353ac90858b4a2f2d20aeae7ededaead5b0)
+    def g1_mul(self, a, k): return self.mul(a, k)
+    def g2_mul(self, a, k): return self.mul(a, k)
+    def g1_to_limbs(self, pt): return self.to_limbs(pt)
+    def g2_to_limbs(self, pt): return self.to_limbs(pt)
+
     # scalar-field NTT (gnark-crypto ecc/bw6-761/fr/fft): GenericDomain only needs r, root, two_adicity, fr_gen
     two_adicity, fr_gen = 46, 15
     root = pow(15, (_P377 - 1) >> 46, _P377)
@@ -385,9 +396,10 @@ BW6_761 = Bw6761()
 class SuiteRng(b.SplitMix64):
     def __init__(self, seed, r):
         super().__init__(seed); self.r = r
+        self.words = (r.bit_length() + 63) // 64           # the width of the field's image: 4 or (BW6-761) 6 stream words
     def next_fr(self):
         v = 0
-        for k in range(4):
+        for k in range(self.words):
             v |= self.next() << (64 * k)
         return v % self.r
 

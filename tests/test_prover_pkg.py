@@ -93,10 +93,12 @@ def test_gpu_error_falls_back_to_cpu_with_reference_message(L, pkg, opy, orc, ca
     assert L.dvn_prover_prove(None, 1, cs.h, None, w.ctypes.data, r.ctypes.data, s.ctypes.data, out.ctypes.data) == 0
     assert "GPU proving failed (" in capfd.readouterr().out
     assert calls == [1] and L.dvn_prover_last_backend() == 2
-    # unsupported curve on the GPU leg -> same fallback (prover_gpu.go:58-60)
+    # a curve without a GPU leg -> same fallback (prover_gpu.go:58-60); all four curves of the reference have one here
+    assert L.dvn_prover_prove(None, 9, cs.h, None, w.ctypes.data, r.ctypes.data, s.ctypes.data, out.ctypes.data) == 0
+    assert "GPU proving not supported for curve unknown" in capfd.readouterr().out
     assert L.dvn_prover_prove(None, 4, cs.h, None, w.ctypes.data, r.ctypes.data, s.ctypes.data, out.ctypes.data) == 0
-    assert "GPU proving not supported for curve bw6_761" in capfd.readouterr().out
-    assert calls == [1, 4]
+    assert "proving key type mismatch for BW6_761" in capfd.readouterr().out
+    assert calls == [1, 9, 4]
     cs.free()
 
 
