@@ -215,12 +215,15 @@ def main():
                                            "round_trip_identity": bool((x0 == x1).all())}
         ctx.free(dx); dom.free(); del x0, x1
         # config 5 (single GPU): statetransition-shaped synthetic Groth16, n = 2^20 constraints, 8 public inputs + constant;
-        # and the same shape on the voteverifier's curve (BLS12-377, 60 such proofs per batch in the reference)
-        for curve, tag in (("bn254", "groth16_synthetic_2^20"), ("bls12377", "groth16_synthetic_bls12377_2^20")):
+        # and the same shape on the voteverifier's curve (BLS12-377, 60 such proofs per batch in the reference) and on the
+        # aggregator's (BW6-761, one per batch)
+        for curve, tag in (("bn254", "groth16_synthetic_2^20"), ("bls12377", "groth16_synthetic_bls12377_2^20"),
+                           ("bw6761", "groth16_synthetic_bw6761_2^20")):
             cs = pkg.R1CS(7, 1 << 20, 9, curve=curve)
             key = pkg.Groth16Key(ctx, cs, 3)
             dw = ctx.to_device(cs.witness())
-            rs = np.array([[5, 0, 0, 0], [7, 0, 0, 0]], dtype=np.uint64)
+            fw = 6 if curve == "bw6761" else 4
+            rs = np.zeros((2, fw), dtype=np.uint64); rs[0, 0], rs[1, 0] = 5, 7
             key.prove(dw, rs[0], rs[1])
             t0 = time.perf_counter()
             for _ in range(5):
