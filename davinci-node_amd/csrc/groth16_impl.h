@@ -401,30 +401,40 @@ template <class SU> static int32_t groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* p
     hipEvent_t e0, e1, e2;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
     auto body = [&]() -> int32_t {
+        typedef typename SU::H1 H1;
+        typedef typename SU::H2 H2;
+        // host part that needs only (r, s) and the key: four of the six scalar multiplications, on threads, under the GPU work
+        const Fe<S> r = fr_from_ext_words<S>(r_mont), s = fr_from_ext_words<S>(s_mont);
+        u32 rw[EW], sw[EW], krw[EW];
+        fr_canonical_words<S>(r, rw); fr_canonical_words<S>(s, sw);
+        fr_canonical_words<S>(fe_neg<S>(fe_mul<S>(r, s)), krw);
+        auto a_dr = std::async(std::launch::async, [&] { return host_mul<H1, S>(hk.delta, rw); });
+        auto a_ds = std::async(std::launch::async, [&] { return host_mul<H1, S>(hk.delta, sw); });
+        auto a_d2s = std::async(std::launch::async, [&] { return host_mul<H2, S>(hk.delta2, sw); });
+        auto a_dk = std::async(std::launch::async, [&] { return host_mul<H1, S>(hk.delta, krw); });
         HIP_TRY(hipEventRecord(e0, st));
         HIP_TRY(hipMemcpyAsync(pk->d_w, witness, m * EB, (flags & 1) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-        // (1) "solve": a = A w, b = B w, c = C w, zero padded to the domain size
+        // (4) filter the wire vector by InfinityA / InfinityB
+        if (pk->nA) k_gather_fr<S::EW><<<(unsigned)((pk->nA + 255) / 256), 256, 0, st>>>(pk->d_w, pk->d_idxA, pk->d_wA, pk->nA);
+        if (pk->nB) k_gather_fr<S::EW><<<(unsigned)((pk->nB + 255) / 256), 256, 0, st>>>(pk->d_w, pk->d_idxB, pk->d_wB, pk->nB);
+        HIP_TRY(hipGetLastError());
+        // (6) the MSMs that need only the wire values go to the two lanes first (a lane waits for what the main stream holds
+        // at submit time, i.e. the gathers) ...
+        typename H1::X mA, mB, mK, mZ; typename H2::X mB2;
+        MsmLane *l2 = nullptr, *l1 = nullptr;
+        TRY(SU::msm_submit_g2(ctx, pk->B2, 0, pk->nB, pk->d_wB, &l2));
+        TRY(SU::msm_submit_g1(ctx, pk->A, 0, pk->nA, pk->d_wA, &l1));
+        // ... while the main stream runs (1) the "solve" a = A w, b = B w, c = C w (zero padded to the domain size) and
+        // (3) h = computeH(a, b, c), which stays on the device as the scalar vector of the Z MSM
         HIP_TRY(hipMemsetAsync(pk->d_abc, 0, 3 * n * EB, st));
         for (int q = 0; q < 3; ++q)
             k_r1cs_matvec<S><<<(unsigned)((pk->n_constraints + 127) / 128), 128, 0, st>>>(pk->d_ptr[q], pk->d_idx[q], pk->d_coef[q], pk->d_w,
                                                                                       pk->d_abc + (size_t)q * n * EW, (u32)pk->n_constraints);
         HIP_TRY(hipGetLastError());
-        // (3) h = computeH(a, b, c), left on the device as the scalar vector of the Z MSM
         TRY(SU::compute_h(ctx, pk->dom, pk->d_abc, pk->d_abc + n * EW, pk->d_abc + 2 * n * EW));
         HIP_TRY(hipEventRecord(e1, st));
-        // (4) filter the wire vector by InfinityA / InfinityB
-        if (pk->nA) k_gather_fr<S::EW><<<(unsigned)((pk->nA + 255) / 256), 256, 0, st>>>(pk->d_w, pk->d_idxA, pk->d_wA, pk->nA);
-        if (pk->nB) k_gather_fr<S::EW><<<(unsigned)((pk->nB + 255) / 256), 256, 0, st>>>(pk->d_w, pk->d_idxB, pk->d_wB, pk->nB);
-        HIP_TRY(hipGetLastError());
-        // (6) the five MSMs
-        typedef typename SU::H1 H1;
-        typedef typename SU::H2 H2;
-        typename H1::X mA, mB, mK, mZ; typename H2::X mB2;
-        // two MSMs in flight: the sort and the latency-bound tail of one run under the accumulate kernel of the other;
-        // the G2 MSM (the longest) goes first and stays in flight while the G1 ones cycle through the second lane
-        MsmLane *l2 = nullptr, *l1 = nullptr;
-        TRY(SU::msm_submit_g2(ctx, pk->B2, 0, pk->nB, pk->d_wB, &l2));
-        TRY(SU::msm_submit_g1(ctx, pk->A, 0, pk->nA, pk->d_wA, &l1));
+        // the G2 MSM (the longest) stays in flight while the G1 ones cycle through the second lane; Z comes last: its submit
+        // makes the lane wait for computeH
         TRY(SU::msm_collect_g1(ctx, l1, &mA));
         TRY(SU::msm_submit_g1(ctx, pk->B, 0, pk->nB, pk->d_wB, &l1));
         TRY(SU::msm_collect_g1(ctx, l1, &mB));
@@ -435,17 +445,7 @@ template <class SU> static int32_t groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* p
         TRY(SU::msm_collect_g2(ctx, l2, &mB2));
         HIP_TRY(hipEventRecord(e2, st));
         HIP_TRY(hipStreamSynchronize(st));
-        // (5)(7) blinding and assembly on the host: O(1) group operations (host_fast.h)
-        const Fe<S> r = fr_from_ext_words<S>(r_mont), s = fr_from_ext_words<S>(s_mont);
-        u32 rw[EW], sw[EW], krw[EW];
-        fr_canonical_words<S>(r, rw); fr_canonical_words<S>(s, sw);
-        fr_canonical_words<S>(fe_neg<S>(fe_mul<S>(r, s)), krw);
-        // the six scalar multiplications are independent in two rounds: run them on host threads (on the curves without
-        // 64-bit-limb host arithmetic one of them costs ~0.5 ms)
-        auto a_dr = std::async(std::launch::async, [&] { return host_mul<H1, S>(hk.delta, rw); });
-        auto a_ds = std::async(std::launch::async, [&] { return host_mul<H1, S>(hk.delta, sw); });
-        auto a_d2s = std::async(std::launch::async, [&] { return host_mul<H2, S>(hk.delta2, sw); });
-        auto a_dk = std::async(std::launch::async, [&] { return host_mul<H1, S>(hk.delta, krw); });
+        // (5)(7) blinding and assembly on the host: O(1) group operations
         const typename H1::X ar = H1::normalize(H1::add(H1::add(mA, hk.alpha), a_dr.get()));
         const typename H1::X bs1 = H1::normalize(H1::add(H1::add(mB, hk.beta), a_ds.get()));
         auto a_ars = std::async(std::launch::async, [&] { return host_mul<H1, S>(ar, sw); });

@@ -157,7 +157,8 @@ int32_t dvn_groth16_pk_free(dvn_ctx* ctx, dvn_groth16_pk* pk);
  * proof_out: Ar (8) | Bs (16) | Krs (8) uint64 = groth16_bn254.Proof{Ar, Bs, Krs} affine images. */
 int32_t dvn_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
                           const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32]);
-/* device time of the last dvn_groth16_prove: computeH part (incl. the matrix-vector "solve"), the five MSMs, total */
+/* device time of the last prove call (any curve): ms_h = start until h is ready on the main stream (witness copy, gathers,
+ * "solve", computeH -- the B2 and A MSMs already run beside it on the two lanes), ms_msm = from there to the last MSM, total */
 int32_t dvn_groth16_last_ms(const dvn_groth16_pk* pk, float* ms_h, float* ms_msm, float* ms_total);
 
 /* Pedersen commitment and its proof of knowledge (gnark-crypto fr/pedersen ProvingKey.Commit /

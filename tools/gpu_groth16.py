@@ -20,7 +20,7 @@ for log_n in [int(a) for a in sys.argv[1:]] or [16, 18, 20]:
     ms = key.last_ms()
     t = time.time(); _, want = orc.groth16_synthetic_expected(7, nc, 9, 3, r, s); t_chk = time.time() - t
     ok = all((pr[k] == want[k]).all() for k in want)
-    print(f"groth16 n=2^{log_n}: r1cs {t_cs:.2f}s setup {t_setup:.2f}s prove wall {dt*1e3:.1f} ms (device: computeH {ms['compute_h']:.2f} ms, 5 MSMs {ms['msm']:.2f} ms) "
+    print(f"groth16 n=2^{log_n}: r1cs {t_cs:.2f}s setup {t_setup:.2f}s prove wall {dt*1e3:.1f} ms (device: h ready after {ms['compute_h']:.2f} ms, then {ms['msm']:.2f} ms) "
           f"-> {1/dt:.2f} proofs/s; sizes {key.sizes}; trapdoor check {'PASS' if ok else 'FAIL'} ({t_chk:.1f}s)", flush=True)
     ctx.free(d); key.free(); cs.free()
 ctx.close()

@@ -18,4 +18,4 @@ for _ in range(5):
     key.prove(dw, rs[0], rs[1])
 dt = (time.time() - t) / 5
 ms = key.last_ms()
-print(f"groth16 {curve} n=2^{log_n}: r1cs {t_cs:.2f}s setup {t_set:.2f}s prove wall {dt*1e3:.1f} ms (device: computeH {ms['compute_h']:.2f} ms, 5 MSMs {ms['msm']:.2f} ms) -> {1/dt:.2f} proofs/s; sizes {key.sizes}", flush=True)
+print(f"groth16 {curve} n=2^{log_n}: r1cs {t_cs:.2f}s setup {t_set:.2f}s prove wall {dt*1e3:.1f} ms (device: h ready after {ms['compute_h']:.2f} ms, then {ms['msm']:.2f} ms) -> {1/dt:.2f} proofs/s; sizes {key.sizes}", flush=True)
