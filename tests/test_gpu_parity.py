@@ -267,6 +267,25 @@ def test_msm_g2_vs_oracle(ctx, orc, n):
     pts.free()
 
 
+def test_msm_g2_every_bucket_heavy(ctx, orc):
+    """Regression for the out-of-range LDS addressing of call-based reductions: with 11-bit windows on 2^16
+    points every one of the 1024 buckets spans ~96 segments, so each block of k_fix_heavy iterates twice.  Plain and expanded
+    evaluation must agree (and with the oracle on a prefix)."""
+    n = 1 << 16
+    pts = ctx.synthetic_g2(5, n)
+    d = ctx.synthetic_scalars(1, 0, n)
+    pts.set_expanded(0)
+    ref = ctx.msm_g2(pts, d, n=n)
+    pts.set_expanded(11)
+    for _ in range(3):
+        assert (ctx.msm_g2(pts, d, n=n) == ref).all()
+    pts.set_expanded(0)
+    sm = np.empty((2000, 4), dtype=np.uint64); ctx.d2h(sm, d)
+    ph = pts.download(0, 2000)
+    assert (aff2(orc, ctx.msm_g2(pts, sm)) == orc.msm_g2(ph, sm)).all()
+    ctx.free(d); pts.free()
+
+
 # ---- NTT ----------------------------------------------------------------------------------------------------------
 def test_ntt_golden_vectors(ctx, vectors, conv):
     doms = {}

@@ -1,0 +1,28 @@
+"""Free device memory before / after repeated create-use-free cycles of every handle type (hipMemGetInfo through torch)."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import __graft_entry__ as g
+pkg = g.load_package()
+ctx = pkg.Context(0)
+def cycle(k):
+    n = 1 << 16
+    pts = ctx.synthetic_g1(k, n); d = ctx.synthetic_scalars(1, k & 1, n); ctx.msm_g1(pts, d, n=n); ctx.free(d); pts.free()
+    q = ctx.synthetic_g2(k, 1 << 14); d = ctx.synthetic_scalars(1, 0, 1 << 14); ctx.msm_g2(q, d, n=1 << 14); ctx.free(d); q.free()
+    dom = ctx.domain(14); x = np.zeros((1 << 14, 4), dtype=np.uint64); ctx.ntt(dom, x, False, 0); dom.free()
+    for curve in ("bn254", "bls12377", "bw6761"):
+        cs = pkg.R1CS(3, 3000, 2, curve=curve); key = pkg.Groth16Key(ctx, cs, 9)
+        fw = 6 if curve == "bw6761" else 4
+        rs = np.zeros((2, fw), dtype=np.uint64); rs[0, 0], rs[1, 0] = 5, 7
+        key.prove(cs.witness(), rs[0], rs[1]); key.free(); cs.free()
+cycle(0); cycle(1)                      # warm up: workspaces of the lanes grow to their final size
+torch.cuda.synchronize()
+f0 = torch.cuda.mem_get_info()[0]
+for k in range(12):
+    cycle(k)
+torch.cuda.synchronize()
+f1 = torch.cuda.mem_get_info()[0]
+print(f"free before {f0 >> 20} MiB, after 12 cycles {f1 >> 20} MiB, delta {(f0 - f1) >> 20} MiB")
+sys.exit(1 if f0 - f1 > (64 << 20) else 0)
