@@ -159,6 +159,7 @@ template <class Cv> static u32 pick_segment(size_t total) {
     size_t seg = total / (slots * 4);
     if (seg < 16) seg = 16;
     if (seg > 128) seg = 128;
+    if (seg > 48 && seg < 96) seg = 64;              // sweep at 2^22 x 13 rows: 64 is 3-7 % faster than its neighbours 56..80
     return (u32)seg;
 }
 
