@@ -469,8 +469,13 @@ static __global__ __launch_bounds__(1024) void k_s2_scatter(const u32* __restric
 
 // ---- HOT KERNEL: segment accumulation -------------------------------------------------------------------
 // lane = (window w, segment k): entries [k*seg, min((k+1)*seg, totals[w])) of window w's sorted list.
+// minimum resident blocks per CU the hot kernel is compiled for: the paired 14-limb Fp2 instantiations land at 262 registers
+// (one wave per SIMD); asking for two waves costs a few spilled values and doubles the occupancy
+template <class Cv> struct AccMinBlocks { static constexpr int value = 1; };
+template <> struct AccMinBlocks<Curve<Fe2P<Fp377Cfg>>> { static constexpr int value = 2; };
+template <> struct AccMinBlocks<Curve<Fe2P<Fp381Cfg>>> { static constexpr int value = 2; };
 template <class Cv>
-__global__ __launch_bounds__(128) void k_accumulate(const u32* __restrict__ points, size_t pts_off,
+__global__ __launch_bounds__(128, AccMinBlocks<Cv>::value) void k_accumulate(const u32* __restrict__ points, size_t pts_off,
                                                     const u32* __restrict__ sorted, const u32* __restrict__ offsets,
                                                     const u32* __restrict__ counts, const u32* __restrict__ totals,
                                                     u32* __restrict__ bucket_sums, u32* __restrict__ edge_first,
