@@ -168,6 +168,7 @@ template <class Cv> static u32 pick_segment(size_t total) {
 // lane_wait() completes them.
 // sliced reduction of giant buckets (k_giant_*): on for every curve
 template <class Cv> struct GiantOk { static constexpr bool value = true; };
+static inline size_t acc_lds_probe() { static const size_t v = []() { const char* e = getenv("DVN_ACC_LDS"); return e ? (size_t)atol(e) : 0; }(); return v; }   // occupancy probe
 static inline u32 giant_threshold() {       // DVN_MSM_GIANT=<segments> overrides (debug / A-B); never below FIX_GIANT: giant_cap assumes it
     static const u32 v = []() { const char* e = getenv("DVN_MSM_GIANT"); const long x = e ? atol(e) : 0; return x > (long)FIX_GIANT ? (u32)x : FIX_GIANT; }();
     return v;
@@ -277,7 +278,7 @@ static int32_t msm_windows_staged(dvn_ctx* ctx, MsmLane& L, const dvn_points* pt
     k_s2_scatter<<<max_pieces, 1024, s2_lds(), st>>>(bin_base, piece_base, hbins, p1_ref, p1_lo, lob, counts, cursor, sorted, offsets);
     DBG_SYNC("k_s2_scatter");
     HIP_TRY(hipEventRecord(L.ev[2], st));
-    k_accumulate<KC><<<(unsigned)(((size_t)nseg * LPP + 127) / 128), 128, 0, st>>>(pts->d, off, sorted, offsets, counts, totals, buckets,
+    k_accumulate<KC><<<(unsigned)(((size_t)nseg * LPP + 127) / 128), 128, acc_lds_probe(), st>>>(pts->d, off, sorted, offsets, counts, totals, buckets,
                                                                           edge_first, edge_last, total, vb, seg, nseg, 1);
     DBG_SYNC("k_accumulate");
     HIP_TRY(hipEventRecord(L.ev[3], st));
@@ -406,7 +407,7 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
     k_s2_scatter<<<max_pieces, 1024, s2_lds(), st>>>(bin_base, piece_base, lb, p1_ref, p1_lo, lob, counts, cursor, sorted, offsets);
     DBG_SYNC("k_s2_scatter");
     HIP_TRY(hipEventRecord(L.ev[2], st));
-    k_accumulate<KC><<<(unsigned)(((size_t)nseg * LPP + 127) / 128), 128, 0, st>>>(pts->d, 0, sorted, offsets, counts, totals, buckets,
+    k_accumulate<KC><<<(unsigned)(((size_t)nseg * LPP + 127) / 128), 128, acc_lds_probe(), st>>>(pts->d, 0, sorted, offsets, counts, totals, buckets,
                                                                           edge_first, edge_last, total, nb, seg, nseg, 1);
     DBG_SYNC("k_accumulate");
     HIP_TRY(hipEventRecord(L.ev[3], st));
