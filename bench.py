@@ -184,14 +184,16 @@ def main():
         m = 1 << min(args.cpu_sample_log_n, args.log_n)
         ph = pts.download(0, m)
         sh = np.ascontiguousarray(sm[:m])
-        orc.msm_g1(ph[:1 << 14], sh[:1 << 14])            # warm the OpenMP pool / page in the library
+        cores = orc.usable_cores()                         # affinity capped by the cgroup CPU quota
+        orc.msm_g1(ph[:1 << 14], sh[:1 << 14], cores)     # warm the OpenMP pool / page in the library
         t0 = time.perf_counter()
-        want = orc.msm_g1(ph, sh)
+        want = orc.msm_g1(ph, sh, cores)
         dt = time.perf_counter() - t0
         got = orc.g1_jac_to_affine(ctx.msm_g1(pts, sh))
-        cpu = {"value": round(m / dt / 1e6, 4), "unit": "Mscalar/s", "cores": orc.num_threads(), "kind": "port",
+        cpu = {"value": round(m / dt / 1e6, 4), "unit": "Mscalar/s", "cores": cores, "kind": "port",
                "sample": f"one G1 MSM over the first 2^{m.bit_length() - 1} points/scalars of the same workload, "
-                         f"{dt:.2f} s wall; own C Pippenger (oracle/bn254_cpu.c), not gnark",
+                         f"{dt:.2f} s wall on {cores} threads (host shows {os.cpu_count()} CPUs; cgroup quota and affinity allow {cores}); "
+                         f"own C Pippenger (oracle/bn254_cpu.c), not gnark",
                "gpu_matches_on_sample": bool((got == want).all())}
 
     # ---- secondary measurements (outside the timed region; N = 1 only): BASELINE configs 3 and 5 --------------

@@ -158,6 +158,27 @@ def num_threads() -> int:
     return int(lib().orc_num_threads())
 
 
+def usable_cores() -> int:
+    """CPU cores this process can actually use: the scheduler affinity capped by the cgroup CPU quota (a container can see
+    256 CPUs and be allowed 16 CPU-seconds per second; more threads than that only adds throttling)."""
+    import math, os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, math.ceil(int(quota) / int(period))))
+        except Exception:
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            n = min(n, max(1, math.ceil(q / per)))
+    except Exception:
+        pass
+    return n
+
+
 def groth16_synthetic_expected(cs_seed: int, n_constraints: int, n_public: int, setup_seed: int, r_mont, s_mont):
     """Closed-form proof from the trapdoor for the synthetic instance.  Returns (witness (m,4), {'Ar','Bs','Krs'})."""
     m = n_public + 4 + n_constraints
