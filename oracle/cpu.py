@@ -25,6 +25,7 @@ def lib():
     global _lib
     if _lib is None:
         build()
+        os.environ.setdefault("OMP_NUM_THREADS", str(usable_cores()))   # before libgomp starts: not one thread per visible CPU
         _lib = C.CDLL(_SO)
         _lib.orc_ntt_roundtrip_seconds.restype = C.c_double
     return _lib
@@ -96,17 +97,17 @@ def g2_jac_to_affine(p): return _un("orc_g2_jac_to_affine", p, 16)
 
 
 def g1_synthetic_points(seed: int, n: int, nthreads: int = 0) -> np.ndarray:
-    out = u64((n, 8)); lib().orc_g1_synthetic_points(C.c_uint64(seed), C.c_size_t(n), _p(out), nthreads); return out
+    out = u64((n, 8)); lib().orc_g1_synthetic_points(C.c_uint64(seed), C.c_size_t(n), _p(out), _nt(nthreads)); return out
 
 
 def g2_synthetic_points(seed: int, n: int, nthreads: int = 0) -> np.ndarray:
-    out = u64((n, 16)); lib().orc_g2_synthetic_points(C.c_uint64(seed), C.c_size_t(n), _p(out), nthreads); return out
+    out = u64((n, 16)); lib().orc_g2_synthetic_points(C.c_uint64(seed), C.c_size_t(n), _p(out), _nt(nthreads)); return out
 
 
 def msm_g1(points: np.ndarray, scalars_mont: np.ndarray, nthreads: int = 0) -> np.ndarray:
     points = np.ascontiguousarray(points, dtype=np.uint64); scalars_mont = np.ascontiguousarray(scalars_mont, dtype=np.uint64)
     out = u64(8)
-    rc = lib().orc_msm_g1(_p(points), C.c_size_t(points.shape[0]), _p(scalars_mont), C.c_size_t(scalars_mont.shape[0]), nthreads, _p(out))
+    rc = lib().orc_msm_g1(_p(points), C.c_size_t(points.shape[0]), _p(scalars_mont), C.c_size_t(scalars_mont.shape[0]), _nt(nthreads), _p(out))
     if rc != 0:
         raise ValueError("len(points) != len(scalars)")
     return out
@@ -116,14 +117,14 @@ def msm_g1_window_sums(points: np.ndarray, scalars_mont: np.ndarray, c: int, nth
     points = np.ascontiguousarray(points, dtype=np.uint64); scalars_mont = np.ascontiguousarray(scalars_mont, dtype=np.uint64)
     nwin = 254 // c + 1
     out = u64((nwin, 16))
-    lib().orc_msm_g1_window_sums(_p(points), _p(scalars_mont), C.c_size_t(points.shape[0]), c, nthreads, _p(out))
+    lib().orc_msm_g1_window_sums(_p(points), _p(scalars_mont), C.c_size_t(points.shape[0]), c, _nt(nthreads), _p(out))
     return out
 
 
 def msm_g2(points: np.ndarray, scalars_mont: np.ndarray, nthreads: int = 0) -> np.ndarray:
     points = np.ascontiguousarray(points, dtype=np.uint64); scalars_mont = np.ascontiguousarray(scalars_mont, dtype=np.uint64)
     out = u64(16)
-    rc = lib().orc_msm_g2(_p(points), C.c_size_t(points.shape[0]), _p(scalars_mont), C.c_size_t(scalars_mont.shape[0]), nthreads, _p(out))
+    rc = lib().orc_msm_g2(_p(points), C.c_size_t(points.shape[0]), _p(scalars_mont), C.c_size_t(scalars_mont.shape[0]), _nt(nthreads), _p(out))
     if rc != 0:
         raise ValueError("len(points) != len(scalars)")
     return out
@@ -134,21 +135,21 @@ def ntt(data: np.ndarray, inverse: bool, decimation: int, coset: bool, nthreads:
     out = np.array(data, dtype=np.uint64, copy=True, order="C")
     n = out.shape[0]; log_n = n.bit_length() - 1
     assert 1 << log_n == n
-    rc = lib().orc_ntt(_p(out), log_n, int(inverse), int(decimation), int(coset), nthreads)
+    rc = lib().orc_ntt(_p(out), log_n, int(inverse), int(decimation), int(coset), _nt(nthreads))
     assert rc == 0
     return out
 
 
 def ntt_roundtrip_seconds(data: np.ndarray, reps: int, nthreads: int = 0) -> float:
     n = data.shape[0]; log_n = n.bit_length() - 1
-    return float(lib().orc_ntt_roundtrip_seconds(_p(data), log_n, reps, nthreads))
+    return float(lib().orc_ntt_roundtrip_seconds(_p(data), log_n, reps, _nt(nthreads)))
 
 
 def compute_h(a, b, c, log_n: int, nthreads: int = 0) -> np.ndarray:
     a = np.ascontiguousarray(a, dtype=np.uint64); b = np.ascontiguousarray(b, dtype=np.uint64); c = np.ascontiguousarray(c, dtype=np.uint64)
     assert a.shape == b.shape == c.shape
     out = u64((1 << log_n, 4))
-    rc = lib().orc_compute_h(_p(a), _p(b), _p(c), C.c_size_t(a.shape[0]), log_n, _p(out), nthreads)
+    rc = lib().orc_compute_h(_p(a), _p(b), _p(c), C.c_size_t(a.shape[0]), log_n, _p(out), _nt(nthreads))
     if rc != 0:
         raise ValueError("len(a) > domain size")
     return out
@@ -156,6 +157,11 @@ def compute_h(a, b, c, log_n: int, nthreads: int = 0) -> np.ndarray:
 
 def num_threads() -> int:
     return int(lib().orc_num_threads())
+
+
+def _nt(nthreads: int) -> int:
+    """0 = as many threads as this process may really use (not OpenMP's default of every visible CPU)."""
+    return nthreads if nthreads > 0 else usable_cores()
 
 
 def usable_cores() -> int:
