@@ -49,7 +49,8 @@ def test_msm_g1_golden_vectors(ctx, orc, vectors, conv):
         pts.free()
 
 
-@pytest.mark.parametrize("n", [1, 2, 33, 1000, 1 << 12, (1 << 14) + 17, 1 << 16, 1 << 18])
+# 2^20 is BASELINE config 2 ("2^20 random scalars/points, bit-exact vs MultiExp"), (1 << 21) + 5 a ragged expanded set
+@pytest.mark.parametrize("n", [1, 2, 33, 1000, 1 << 12, (1 << 14) + 17, 1 << 16, 1 << 18, 1 << 20, (1 << 21) + 5])
 @pytest.mark.parametrize("kind", [0, 1])
 def test_msm_g1_vs_oracle(ctx, orc, n, kind):
     ph = orc.g1_synthetic_points(0xDA71C1, n)
@@ -257,7 +258,7 @@ def test_msm_g2_golden_vectors(ctx, orc, vectors, conv):
         pts.free()
 
 
-@pytest.mark.parametrize("n", [1, 17, 1000, 1 << 13, (1 << 17) + 3])          # the last one is an expanded set (c = 18)
+@pytest.mark.parametrize("n", [1, 17, 1000, 1 << 13, (1 << 17) + 3, 1 << 19])          # the last two are expanded sets
 def test_msm_g2_vs_oracle(ctx, orc, n):
     ph = orc.g2_synthetic_points(5, n)
     pts = ctx.upload_g2(ph)
@@ -298,7 +299,7 @@ def test_ntt_golden_vectors(ctx, vectors, conv):
         d.free()
 
 
-@pytest.mark.parametrize("log_n", [1, 2, 3, 5, 8, 9, 11, 12, 16, 17, 19])
+@pytest.mark.parametrize("log_n", [1, 2, 3, 5, 8, 9, 11, 12, 16, 17, 19, 22])
 def test_ntt_all_modes_vs_oracle(ctx, orc, log_n):
     n = 1 << log_n
     dom = ctx.domain(log_n)
@@ -336,6 +337,11 @@ def test_ntt_full_size_properties(ctx, orc, pkg):
     assert (orc.fr_add(half, one) == 0).all()
     quarter = y[2]                                                # rev(2) = n/4 -> w^(n/4), a 4th root of unity
     assert (orc.fr_mul(quarter, quarter) == half).all()
+    # and the transform itself, bit for bit against the CPU restatement: forward DIF and inverse DIT on the coset
+    ctx.h2d(dx, x); ctx.ntt(dom, dx, False, pkg.DIF, False); ctx.d2h(y, dx)
+    assert (y == orc.ntt(x, False, pkg.DIF, False)).all()
+    ctx.ntt(dom, dx, True, pkg.DIT, True); ctx.d2h(y, dx)
+    assert (y == orc.ntt(orc.ntt(x, False, pkg.DIF, False), True, pkg.DIT, True)).all()
     ctx.free(dx); dom.free()
 
 
@@ -348,7 +354,7 @@ def test_compute_h_golden_vectors(ctx, vectors, conv):
         dom.free()
 
 
-@pytest.mark.parametrize("log_n,m", [(3, 5), (10, 1000), (16, (1 << 16) - 3), (18, 1 << 18)])
+@pytest.mark.parametrize("log_n,m", [(3, 5), (10, 1000), (16, (1 << 16) - 3), (18, 1 << 18), (21, (1 << 21) - 77)])
 def test_compute_h_vs_oracle(ctx, orc, log_n, m):
     dom = ctx.domain(log_n)
     a, b, c = orc.scalars(3, 0, m), orc.scalars(4, 0, m), orc.scalars(5, 0, m)
