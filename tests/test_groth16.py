@@ -46,7 +46,8 @@ def test_groth16_small_instance_vs_python_oracle(ctx, pkg, opy):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_constraints,n_public", [(100, 1), (1 << 12, 9), ((1 << 14) - 5, 9), (1 << 16, 9)])
+# the last case is the statetransition-shaped instance of BASELINE config 5 (bench extras): n = 2^20, 8 public inputs + constant
+@pytest.mark.parametrize("n_constraints,n_public", [(100, 1), (1 << 12, 9), ((1 << 14) - 5, 9), (1 << 16, 9), (1 << 20, 9)])
 def test_groth16_trapdoor_identity(ctx, pkg, opy, orc, n_constraints, n_public):
     cs = pkg.R1CS(7, n_constraints, n_public)
     key = pkg.Groth16Key(ctx, cs, 3)
