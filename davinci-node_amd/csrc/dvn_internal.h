@@ -32,7 +32,7 @@ struct MsmLane {
     int curve = 0; bool expanded = false; u32 c = 0, nwin = 0, W = 0; u32 seq = 0;
     float ms[2] = {0.f, 0.f};
 };
-constexpr int DVN_LANES = 2;
+constexpr int DVN_LANES = 4;
 constexpr size_t DVN_HSUMS_WORDS = 64 * 128;    // up to 64 windows of the widest xyzz image (BLS12-377 G2: 96 words)
 
 struct dvn_ctx {

@@ -418,12 +418,14 @@ template <class SU> static int32_t groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* p
         if (pk->nA) k_gather_fr<S::EW><<<(unsigned)((pk->nA + 255) / 256), 256, 0, st>>>(pk->d_w, pk->d_idxA, pk->d_wA, pk->nA);
         if (pk->nB) k_gather_fr<S::EW><<<(unsigned)((pk->nB + 255) / 256), 256, 0, st>>>(pk->d_w, pk->d_idxB, pk->d_wB, pk->nB);
         HIP_TRY(hipGetLastError());
-        // (6) the MSMs that need only the wire values go to the two lanes first (a lane waits for what the main stream holds
-        // at submit time, i.e. the gathers) ...
+        // (6) the four MSMs that need only the wire values go to four lanes at once (a lane waits for what the main stream
+        // holds at submit time, i.e. the gathers): their sorts and latency-bound bucket reductions overlap each other ...
         typename H1::X mA, mB, mK, mZ; typename H2::X mB2;
-        MsmLane *l2 = nullptr, *l1 = nullptr;
+        MsmLane *l2 = nullptr, *lA = nullptr, *lB = nullptr, *lK = nullptr, *lZ = nullptr;
         TRY(SU::msm_submit_g2(ctx, pk->B2, 0, pk->nB, pk->d_wB, &l2));
-        TRY(SU::msm_submit_g1(ctx, pk->A, 0, pk->nA, pk->d_wA, &l1));
+        TRY(SU::msm_submit_g1(ctx, pk->A, 0, pk->nA, pk->d_wA, &lA));
+        TRY(SU::msm_submit_g1(ctx, pk->B, 0, pk->nB, pk->d_wB, &lB));
+        TRY(SU::msm_submit_g1(ctx, pk->K, 0, m - pk->n_public, pk->d_w + pk->n_public * EW, &lK));
         // ... while the main stream runs (1) the "solve" a = A w, b = B w, c = C w (zero padded to the domain size) and
         // (3) h = computeH(a, b, c), which stays on the device as the scalar vector of the Z MSM
         HIP_TRY(hipMemsetAsync(pk->d_abc, 0, 3 * n * EB, st));
@@ -433,15 +435,12 @@ template <class SU> static int32_t groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* p
         HIP_TRY(hipGetLastError());
         TRY(SU::compute_h(ctx, pk->dom, pk->d_abc, pk->d_abc + n * EW, pk->d_abc + 2 * n * EW));
         HIP_TRY(hipEventRecord(e1, st));
-        // the G2 MSM (the longest) stays in flight while the G1 ones cycle through the second lane; Z comes last: its submit
-        // makes the lane wait for computeH
-        TRY(SU::msm_collect_g1(ctx, l1, &mA));
-        TRY(SU::msm_submit_g1(ctx, pk->B, 0, pk->nB, pk->d_wB, &l1));
-        TRY(SU::msm_collect_g1(ctx, l1, &mB));
-        TRY(SU::msm_submit_g1(ctx, pk->K, 0, m - pk->n_public, pk->d_w + pk->n_public * EW, &l1));
-        TRY(SU::msm_collect_g1(ctx, l1, &mK));
-        TRY(SU::msm_submit_g1(ctx, pk->Z, 0, n - 1, pk->d_abc, &l1));               // h[:n-1] against Z[:n-1]
-        TRY(SU::msm_collect_g1(ctx, l1, &mZ));
+        // Z takes the first lane that frees up: its submit makes the lane wait for computeH
+        TRY(SU::msm_collect_g1(ctx, lA, &mA));
+        TRY(SU::msm_submit_g1(ctx, pk->Z, 0, n - 1, pk->d_abc, &lZ));               // h[:n-1] against Z[:n-1]
+        TRY(SU::msm_collect_g1(ctx, lB, &mB));
+        TRY(SU::msm_collect_g1(ctx, lK, &mK));
+        TRY(SU::msm_collect_g1(ctx, lZ, &mZ));
         TRY(SU::msm_collect_g2(ctx, l2, &mB2));
         HIP_TRY(hipEventRecord(e2, st));
         HIP_TRY(hipStreamSynchronize(st));

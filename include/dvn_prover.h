@@ -86,8 +86,8 @@ int32_t dvn_msm_g1(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, co
                    uint32_t flags, uint64_t out_jac[12]);
 int32_t dvn_msm_g2(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars_mont,
                    uint32_t flags, uint64_t out_jac[24]);
-/* Asynchronous pair: _submit queues the MSM on one of the context's two lanes (own stream + workspace) and returns a
- * ticket; _collect waits for it and writes the result.  With two MSMs in flight the sort and the latency-bound tail of
+/* Asynchronous pair: _submit queues the MSM on one of the context's four lanes (own stream + workspace) and returns a
+ * ticket; _collect waits for it and writes the result.  With several MSMs in flight the sort and the latency-bound tail of
  * one run under the accumulate kernel of the other (measured +10 % throughput at 2^22, +19 % at 2^20, +52 % at 2^18).
  * Host scalars are copied before _submit returns; DEVICE scalars must stay untouched until _collect.  At most two
  * tickets may be outstanding per context. */
@@ -158,7 +158,7 @@ int32_t dvn_groth16_pk_free(dvn_ctx* ctx, dvn_groth16_pk* pk);
 int32_t dvn_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
                           const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32]);
 /* device time of the last prove call (any curve): ms_h = start until h is ready on the main stream (witness copy, gathers,
- * "solve", computeH -- the B2 and A MSMs already run beside it on the two lanes), ms_msm = from there to the last MSM, total */
+ * "solve", computeH -- the B2, A, B1 and K MSMs already run beside it on the four lanes), ms_msm = from there to the last MSM, total */
 int32_t dvn_groth16_last_ms(const dvn_groth16_pk* pk, float* ms_h, float* ms_msm, float* ms_total);
 
 /* Pedersen commitment and its proof of knowledge (gnark-crypto fr/pedersen ProvingKey.Commit /

@@ -163,9 +163,9 @@ def test_msm_g1_full_size_closed_form(ctx, orc, opy, log_n):
     pts.free()
 
 
-def test_msm_async_two_in_flight(ctx, orc, pkg):
-    """submit/collect: two MSMs in flight on the two lanes, results identical to the synchronous call; a third submit
-    is refused until a ticket is collected."""
+def test_msm_async_in_flight(ctx, orc, pkg):
+    """submit/collect: MSMs in flight on the context's four lanes, results identical to the synchronous call; a fifth
+    submit is refused until a ticket is collected."""
     n = 20000
     ph = orc.g1_synthetic_points(41, n); pts = ctx.upload_g1(ph)
     a, b = orc.scalars(1, 0, n), orc.scalars(2, 1, n)
@@ -173,11 +173,14 @@ def test_msm_async_two_in_flight(ctx, orc, pkg):
     for _ in range(3):
         t1 = ctx.msm_g1_submit(pts, da, n=n)
         t2 = ctx.msm_g1_submit(pts, db, n=n)
-        assert {t1, t2} == {1, 2}
+        t3 = ctx.msm_g1_submit(pts, da, n=n)
+        t4 = ctx.msm_g1_submit(pts, db, n=n)
+        assert {t1, t2, t3, t4} == {1, 2, 3, 4}
         with pytest.raises(pkg.DvnError):
             ctx.msm_g1_submit(pts, da, n=n)
-        r2 = ctx.msm_g1_collect(t2); r1 = ctx.msm_g1_collect(t1)
+        r4 = ctx.msm_g1_collect(t4); r2 = ctx.msm_g1_collect(t2); r1 = ctx.msm_g1_collect(t1); r3 = ctx.msm_g1_collect(t3)
         assert (aff1(orc, r1) == orc.msm_g1(ph, a)).all() and (aff1(orc, r2) == orc.msm_g1(ph, b)).all()
+        assert (r3 == r1).all() and (r4 == r2).all()
     with pytest.raises(pkg.DvnError):
         ctx.msm_g1_collect(1)                       # nothing outstanding
     # host scalars may be reused as soon as submit returns
