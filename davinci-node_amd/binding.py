@@ -88,6 +88,8 @@ def load_library():
         "dvn_groth16_pk_free": (i32, [vp, vp]),
         "dvn_groth16_prove": (i32, [vp, vp, vp, u32, vp, vp, vp]),
         "dvn_groth16_last_ms": (i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+        "dvn_groth16_prove_shard": (i32, [vp, vp, vp, u32, u32, u32, vp]),
+        "dvn_groth16_prove_combine": (i32, [vp, vp, u32, vp, vp, vp]),
         "dvn_groth16_proof_abi_encode": (i32, [vp, vp, vp, vp]),
         "dvn_pedersen_commit": (i32, [vp, vp, vp, vp, sz, u32, vp, vp]),
         "dvn_bls12377_points_upload_g1": (i32, [vp, vp, sz, C.POINTER(vp)]),
@@ -151,7 +153,7 @@ EXPORTED_SYMBOLS = [
     "dvn_points_synthetic_g2", "dvn_scalars_synthetic", "dvn_points_set_expanded", "dvn_points_download", "dvn_points_len", "dvn_points_free", "dvn_msm_g1", "dvn_msm_g2",
     "dvn_msm_g1_submit", "dvn_msm_g1_collect", "dvn_msm_g2_submit", "dvn_msm_g2_collect", "dvn_msm_plan", "dvn_msm_plan_points", "dvn_msm_g1_windows", "dvn_msm_g1_windows_submit", "dvn_msm_g1_windows_collect", "dvn_msm_combine_g1", "dvn_ntt_domain", "dvn_ntt_domain_free", "dvn_ntt",
     "dvn_groth16_compute_h", "dvn_last_kernel_ms", "dvn_r1cs_synthetic", "dvn_r1cs_info", "dvn_r1cs_witness", "dvn_r1cs_free",
-    "dvn_groth16_setup", "dvn_groth16_pk_info", "dvn_groth16_pk_free", "dvn_groth16_prove", "dvn_groth16_last_ms",
+    "dvn_groth16_setup", "dvn_groth16_pk_info", "dvn_groth16_pk_free", "dvn_groth16_prove", "dvn_groth16_last_ms", "dvn_groth16_prove_shard", "dvn_groth16_prove_combine",
     "dvn_groth16_proof_abi_encode", "dvn_pedersen_commit",
     "dvn_bls12377_points_upload_g1", "dvn_bls12377_points_upload_g2", "dvn_bls12377_points_synthetic_g1", "dvn_bls12377_points_download",
     "dvn_bls12377_scalars_synthetic", "dvn_bls12377_msm_g1", "dvn_bls12377_msm_g2", "dvn_bls12377_ntt_domain", "dvn_bls12377_ntt", "dvn_bls12377_groth16_compute_h",
@@ -442,6 +444,25 @@ class Groth16Key:
             witness = np.ascontiguousarray(witness, dtype=np.uint64); wp, fl = _host(witness), 0
         self.ctx._chk(getattr(self.ctx.L, self._prefix + "groth16_prove")(self.ctx.h, self.h, wp, fl, _host(r_mont), _host(s_mont), _host(out)))
         return {"Ar": out[0:a1].copy(), "Bs": out[a1:a1 + a2].copy(), "Krs": out[a1 + a2:2 * a1 + a2].copy()}
+
+    def prove_shard(self, witness, rank: int, world: int) -> np.ndarray:
+        """This rank's partial results of the five MSMs (BN254 keys): (72,) uint64 to be all-gathered."""
+        assert self.curve == "bn254"
+        out = np.zeros(72, dtype=np.uint64)
+        if isinstance(witness, (int, np.integer)):
+            wp, fl = C.c_void_p(int(witness)), 1
+        else:
+            witness = np.ascontiguousarray(witness, dtype=np.uint64); wp, fl = _host(witness), 0
+        self.ctx._chk(self.ctx.L.dvn_groth16_prove_shard(self.ctx.h, self.h, wp, fl, rank, world, _host(out)))
+        return out
+
+    def prove_combine(self, partials: np.ndarray, r_mont: np.ndarray, s_mont: np.ndarray) -> dict:
+        """partials: (world, 72) uint64 as gathered from the ranks.  Host only."""
+        partials = np.ascontiguousarray(partials, dtype=np.uint64).reshape(-1, 72)
+        r_mont = np.ascontiguousarray(r_mont, dtype=np.uint64); s_mont = np.ascontiguousarray(s_mont, dtype=np.uint64)
+        out = np.zeros(32, dtype=np.uint64)
+        self.ctx._chk(self.ctx.L.dvn_groth16_prove_combine(self.h, _host(partials), partials.shape[0], _host(r_mont), _host(s_mont), _host(out)))
+        return {"Ar": out[0:8].copy(), "Bs": out[8:24].copy(), "Krs": out[24:32].copy()}
 
     def last_ms(self):
         a, b, c = C.c_float(), C.c_float(), C.c_float()

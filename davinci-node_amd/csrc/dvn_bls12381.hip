@@ -64,6 +64,8 @@ struct SuiteBls12381 {
     static int32_t msm_submit_g2(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, MsmLane** l) {
         return msm_submit<G2_381>(ctx, p, off, n, (const uint64_t*)s, DVN_MSM_SCALARS_ON_DEVICE, l);
     }
+    static int32_t msm_rows_submit_g1(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, u32 lo, u32 hi, MsmLane** l) { return msm_rows_submit<G1_381>(ctx, p, off, n, s, lo, hi, l); }
+    static int32_t msm_rows_submit_g2(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, u32 lo, u32 hi, MsmLane** l) { return msm_rows_submit<G2_381>(ctx, p, off, n, s, lo, hi, l); }
     static int32_t msm_collect_g1(dvn_ctx* ctx, MsmLane* l, H1::X* out) { return msm_collect<G1_381>(ctx, *l, out); }
     static int32_t msm_collect_g2(dvn_ctx* ctx, MsmLane* l, H2::X* out) { return msm_collect<G2_381>(ctx, *l, out); }
 };

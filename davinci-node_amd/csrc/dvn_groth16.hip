@@ -18,6 +18,8 @@ struct SuiteBn254 {
     static int32_t compute_h(dvn_ctx* ctx, const dvn_domain* dom, u32* a, u32* b, u32* c) { return dvn_internal_compute_h_dev(ctx, dom, a, b, c); }
     static int32_t msm_submit_g1(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, MsmLane** l) { return dvn_internal_msm_submit_g1(ctx, p, off, n, s, l); }
     static int32_t msm_submit_g2(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, MsmLane** l) { return dvn_internal_msm_submit_g2(ctx, p, off, n, s, l); }
+    static int32_t msm_rows_submit_g1(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, u32 lo, u32 hi, MsmLane** l) { return dvn_internal_msm_rows_submit_g1(ctx, p, off, n, s, lo, hi, l); }
+    static int32_t msm_rows_submit_g2(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, u32 lo, u32 hi, MsmLane** l) { return dvn_internal_msm_rows_submit_g2(ctx, p, off, n, s, lo, hi, l); }
     static int32_t msm_collect_g1(dvn_ctx* ctx, MsmLane* l, H1::X* out) { return dvn_internal_msm_collect_g1(ctx, l, out); }
     static int32_t msm_collect_g2(dvn_ctx* ctx, MsmLane* l, H2::X* out) { return dvn_internal_msm_collect_g2(ctx, l, out); }
 };
@@ -29,6 +31,18 @@ extern "C" int32_t dvn_groth16_setup(dvn_ctx* ctx, const dvn_r1cs* cs, uint64_t 
 extern "C" int32_t dvn_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
                                      const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32]) {
     return groth16_prove<SuiteBn254>(ctx, pk, witness, flags, r_mont, s_mont, proof_out);
+}
+
+// Sharded proving (BASELINE config 5: the proof's MSMs sharded across the GPUs of a node): rank `rank` of `world` computes its
+// rows of the five MSMs (dvn_groth16_prove_shard, 72 uint64 of partial results), the ranks all-gather them, and every rank (or
+// one) assembles the proof on the host (dvn_groth16_prove_combine).  Needs expanded key sets (>= 2^15 points each).
+extern "C" int32_t dvn_groth16_prove_shard(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
+                                           uint32_t rank, uint32_t world, uint64_t partial_out[72]) {
+    return groth16_prove_shard<SuiteBn254>(ctx, pk, witness, flags, rank, world, partial_out);
+}
+extern "C" int32_t dvn_groth16_prove_combine(const dvn_groth16_pk* pk, const uint64_t* partials, uint32_t world,
+                                             const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32]) {
+    return groth16_prove_combine<SuiteBn254>(pk, partials, world, r_mont, s_mont, proof_out);
 }
 
 // ---- curve-independent handles ------------------------------------------------------------------------------------

@@ -183,6 +183,9 @@ int32_t dvn_internal_msm_submit_g1(dvn_ctx* ctx, const dvn_points* pts, size_t o
 int32_t dvn_internal_msm_submit_g2(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, MsmLane** lane);
 int32_t dvn_internal_msm_collect_g1(dvn_ctx* ctx, MsmLane* lane, dvn_host::HG1::X* out);
 int32_t dvn_internal_msm_collect_g2(dvn_ctx* ctx, MsmLane* lane, dvn_host::HG2::X* out);
+// rows [lo, hi) of an expanded set: one partial result per call (sharded Groth16)
+int32_t dvn_internal_msm_rows_submit_g1(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, u32 lo, u32 hi, MsmLane** lane);
+int32_t dvn_internal_msm_rows_submit_g2(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, u32 lo, u32 hi, MsmLane** lane);
 // computeH on three device vectors of n = 2^log_n elements (already zero padded); result left in da (dvn_ntt.hip)
 int32_t dvn_internal_compute_h_dev(dvn_ctx* ctx, const dvn_domain* dom, u32* da, u32* db, u32* dc);
 uint32_t dvn_internal_domain_log_n(const dvn_domain* dom);

@@ -381,37 +381,29 @@ template <class SU> static int32_t groth16_setup(dvn_ctx* ctx, const dvn_r1cs* c
 // ------------------------------------------------------------------------------------------------------
 // Prove
 // ------------------------------------------------------------------------------------------------------
-// witness: m x 4 uint64 gnark Montgomery words (host, or device with flags & 1); r_mont/s_mont: the blinding
-// factors gnark draws from crypto/rand, injected so results are reproducible.  proof_out: Ar | Bs | Krs as affine
-// Montgomery images exactly as gnark's Proof holds them (G1Affine, G2Affine, G1Affine of the curve).
-template <class SU> static int32_t groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
-                                                 const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out) {
+template <class SU> struct MsmResults { typename SU::H1::X mA, mB, mK, mZ; typename SU::H2::X mB2; };
+
+// Device part of a proof.  world == 1: the five full MSMs.  world > 1 (sharded proving, SURVEY.md §8e / BASELINE config 5):
+// this rank's slice of the ROWS of every (expanded) key set -- the partial results of all ranks add up to the MSMs; the
+// "solve" and computeH are replicated on every rank.  Caller holds ctx->mu.
+template <class SU> static int32_t groth16_device(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
+                                                  u32 rank, u32 world, MsmResults<SU>* out) {
     typedef typename SU::FrC S;
-    typedef typename SU::G1T G1;
-    typedef typename SU::G2T G2;
     constexpr u32 EW = S::EW;
     constexpr size_t EB = (size_t)EW * 4;
-    TRY(enter(ctx));
-    if (!pk || !witness || !r_mont || !s_mont || !proof_out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
-    if (pk->suite != SU::SUITE) return fail(DVN_ERR_INVALID_ARG, "proving key belongs to another curve");
-    const HostKey<SU>& hk = *(const HostKey<SU>*)pk->hk;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     hipStream_t st = ctx->stream;
     const size_t n = pk->n, m = pk->m;
     hipEvent_t e0, e1, e2;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
+    auto submit_g1 = [&](const dvn_points* p, size_t cnt, const u32* sc, MsmLane** l) -> int32_t {
+        if (world == 1) return SU::msm_submit_g1(ctx, p, 0, cnt, sc, l);
+        return SU::msm_rows_submit_g1(ctx, p, 0, cnt, sc, rank * p->nexp / world, (rank + 1) * p->nexp / world, l);
+    };
+    auto submit_g2 = [&](const dvn_points* p, size_t cnt, const u32* sc, MsmLane** l) -> int32_t {
+        if (world == 1) return SU::msm_submit_g2(ctx, p, 0, cnt, sc, l);
+        return SU::msm_rows_submit_g2(ctx, p, 0, cnt, sc, rank * p->nexp / world, (rank + 1) * p->nexp / world, l);
+    };
     auto body = [&]() -> int32_t {
-        typedef typename SU::H1 H1;
-        typedef typename SU::H2 H2;
-        // host part that needs only (r, s) and the key: four of the six scalar multiplications, on threads, under the GPU work
-        const Fe<S> r = fr_from_ext_words<S>(r_mont), s = fr_from_ext_words<S>(s_mont);
-        u32 rw[EW], sw[EW], krw[EW];
-        fr_canonical_words<S>(r, rw); fr_canonical_words<S>(s, sw);
-        fr_canonical_words<S>(fe_neg<S>(fe_mul<S>(r, s)), krw);
-        auto a_dr = std::async(std::launch::async, [&] { return host_mul<H1, S>(hk.delta, rw); });
-        auto a_ds = std::async(std::launch::async, [&] { return host_mul<H1, S>(hk.delta, sw); });
-        auto a_d2s = std::async(std::launch::async, [&] { return host_mul<H2, S>(hk.delta2, sw); });
-        auto a_dk = std::async(std::launch::async, [&] { return host_mul<H1, S>(hk.delta, krw); });
         HIP_TRY(hipEventRecord(e0, st));
         HIP_TRY(hipMemcpyAsync(pk->d_w, witness, m * EB, (flags & 1) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
         // (4) filter the wire vector by InfinityA / InfinityB
@@ -420,12 +412,11 @@ template <class SU> static int32_t groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* p
         HIP_TRY(hipGetLastError());
         // (6) the four MSMs that need only the wire values go to four lanes at once (a lane waits for what the main stream
         // holds at submit time, i.e. the gathers): their sorts and latency-bound bucket reductions overlap each other ...
-        typename H1::X mA, mB, mK, mZ; typename H2::X mB2;
         MsmLane *l2 = nullptr, *lA = nullptr, *lB = nullptr, *lK = nullptr, *lZ = nullptr;
-        TRY(SU::msm_submit_g2(ctx, pk->B2, 0, pk->nB, pk->d_wB, &l2));
-        TRY(SU::msm_submit_g1(ctx, pk->A, 0, pk->nA, pk->d_wA, &lA));
-        TRY(SU::msm_submit_g1(ctx, pk->B, 0, pk->nB, pk->d_wB, &lB));
-        TRY(SU::msm_submit_g1(ctx, pk->K, 0, m - pk->n_public, pk->d_w + pk->n_public * EW, &lK));
+        TRY(submit_g2(pk->B2, pk->nB, pk->d_wB, &l2));
+        TRY(submit_g1(pk->A, pk->nA, pk->d_wA, &lA));
+        TRY(submit_g1(pk->B, pk->nB, pk->d_wB, &lB));
+        TRY(submit_g1(pk->K, m - pk->n_public, pk->d_w + pk->n_public * EW, &lK));
         // ... while the main stream runs (1) the "solve" a = A w, b = B w, c = C w (zero padded to the domain size) and
         // (3) h = computeH(a, b, c), which stays on the device as the scalar vector of the Z MSM
         HIP_TRY(hipMemsetAsync(pk->d_abc, 0, 3 * n * EB, st));
@@ -436,32 +427,14 @@ template <class SU> static int32_t groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* p
         TRY(SU::compute_h(ctx, pk->dom, pk->d_abc, pk->d_abc + n * EW, pk->d_abc + 2 * n * EW));
         HIP_TRY(hipEventRecord(e1, st));
         // Z takes the first lane that frees up: its submit makes the lane wait for computeH
-        TRY(SU::msm_collect_g1(ctx, lA, &mA));
-        TRY(SU::msm_submit_g1(ctx, pk->Z, 0, n - 1, pk->d_abc, &lZ));               // h[:n-1] against Z[:n-1]
-        TRY(SU::msm_collect_g1(ctx, lB, &mB));
-        TRY(SU::msm_collect_g1(ctx, lK, &mK));
-        TRY(SU::msm_collect_g1(ctx, lZ, &mZ));
-        TRY(SU::msm_collect_g2(ctx, l2, &mB2));
+        TRY(SU::msm_collect_g1(ctx, lA, &out->mA));
+        TRY(submit_g1(pk->Z, n - 1, pk->d_abc, &lZ));                                // h[:n-1] against Z[:n-1]
+        TRY(SU::msm_collect_g1(ctx, lB, &out->mB));
+        TRY(SU::msm_collect_g1(ctx, lK, &out->mK));
+        TRY(SU::msm_collect_g1(ctx, lZ, &out->mZ));
+        TRY(SU::msm_collect_g2(ctx, l2, &out->mB2));
         HIP_TRY(hipEventRecord(e2, st));
         HIP_TRY(hipStreamSynchronize(st));
-        // (5)(7) blinding and assembly on the host: O(1) group operations
-        const typename H1::X ar = H1::normalize(H1::add(H1::add(mA, hk.alpha), a_dr.get()));
-        const typename H1::X bs1 = H1::normalize(H1::add(H1::add(mB, hk.beta), a_ds.get()));
-        auto a_ars = std::async(std::launch::async, [&] { return host_mul<H1, S>(ar, sw); });
-        auto a_bsr = std::async(std::launch::async, [&] { return host_mul<H1, S>(bs1, rw); });
-        const typename H2::X bs = H2::add(H2::add(mB2, hk.beta2), a_d2s.get());
-        typename H1::X krs = H1::add(mK, mZ);
-        krs = H1::add(krs, a_dk.get());
-        krs = H1::add(krs, a_ars.get());
-        krs = H1::add(krs, a_bsr.get());
-        constexpr size_t A1 = G1::AW / 2, A2 = G2::AW / 2;            // uint64 words of an affine image
-        uint64_t j1[3 * A1 / 2 + 1], j2[3 * A2 / 2 + 1];
-        H1::write_jac(ar, j1); memcpy(proof_out, j1, A1 * 8);
-        H2::write_jac(bs, j2); memcpy(proof_out + A1, j2, A2 * 8);
-        H1::write_jac(krs, j1); memcpy(proof_out + A1 + A2, j1, A1 * 8);
-        if (H1::is_inf(ar)) memset(proof_out, 0, A1 * 8);             // gnark's affine infinity is (0, 0)
-        if (H2::is_inf(bs)) memset(proof_out + A1, 0, A2 * 8);
-        if (H1::is_inf(krs)) memset(proof_out + A1 + A2, 0, A1 * 8);
         HIP_TRY(hipEventElapsedTime(&pk->ms_h, e0, e1));
         HIP_TRY(hipEventElapsedTime(&pk->ms_msm, e1, e2));
         HIP_TRY(hipEventElapsedTime(&pk->ms_total, e0, e2));
@@ -470,4 +443,123 @@ template <class SU> static int32_t groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* p
     int32_t rc = body();
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
     return rc;
+}
+
+// (5)(7) blinding and assembly on the host: O(1) group operations.  The four scalar multiplications that need only (r, s) and
+// the key start on threads right away (Blind), so they run under the GPU work of the same proof.
+template <class SU> struct Blind {
+    typedef typename SU::FrC S;
+    typedef typename SU::H1 H1;
+    typedef typename SU::H2 H2;
+    u32 rw[S::EW], sw[S::EW], krw[S::EW];
+    std::future<typename H1::X> dr, ds, dk;
+    std::future<typename H2::X> d2s;
+    Blind(const HostKey<SU>& hk, const uint64_t* r_mont, const uint64_t* s_mont) {
+        const Fe<S> r = fr_from_ext_words<S>(r_mont), s = fr_from_ext_words<S>(s_mont);
+        fr_canonical_words<S>(r, rw); fr_canonical_words<S>(s, sw);
+        fr_canonical_words<S>(fe_neg<S>(fe_mul<S>(r, s)), krw);
+        dr = std::async(std::launch::async, [this, &hk] { return host_mul<H1, S>(hk.delta, rw); });
+        ds = std::async(std::launch::async, [this, &hk] { return host_mul<H1, S>(hk.delta, sw); });
+        d2s = std::async(std::launch::async, [this, &hk] { return host_mul<H2, S>(hk.delta2, sw); });
+        dk = std::async(std::launch::async, [this, &hk] { return host_mul<H1, S>(hk.delta, krw); });
+    }
+};
+template <class SU> static void groth16_assemble(const HostKey<SU>& hk, const MsmResults<SU>& R, Blind<SU>& bl, uint64_t* proof_out) {
+    typedef typename SU::FrC S;
+    typedef typename SU::G1T G1;
+    typedef typename SU::G2T G2;
+    typedef typename SU::H1 H1;
+    typedef typename SU::H2 H2;
+    const typename H1::X ar = H1::normalize(H1::add(H1::add(R.mA, hk.alpha), bl.dr.get()));
+    const typename H1::X bs1 = H1::normalize(H1::add(H1::add(R.mB, hk.beta), bl.ds.get()));
+    auto a_ars = std::async(std::launch::async, [&] { return host_mul<H1, S>(ar, bl.sw); });
+    auto a_bsr = std::async(std::launch::async, [&] { return host_mul<H1, S>(bs1, bl.rw); });
+    const typename H2::X bs = H2::add(H2::add(R.mB2, hk.beta2), bl.d2s.get());
+    typename H1::X krs = H1::add(R.mK, R.mZ);
+    krs = H1::add(krs, bl.dk.get());
+    krs = H1::add(krs, a_ars.get());
+    krs = H1::add(krs, a_bsr.get());
+    constexpr size_t A1 = G1::AW / 2, A2 = G2::AW / 2;            // uint64 words of an affine image
+    uint64_t j1[3 * A1 / 2 + 1], j2[3 * A2 / 2 + 1];
+    H1::write_jac(ar, j1); memcpy(proof_out, j1, A1 * 8);
+    H2::write_jac(bs, j2); memcpy(proof_out + A1, j2, A2 * 8);
+    H1::write_jac(krs, j1); memcpy(proof_out + A1 + A2, j1, A1 * 8);
+    if (H1::is_inf(ar)) memset(proof_out, 0, A1 * 8);             // gnark's affine infinity is (0, 0)
+    if (H2::is_inf(bs)) memset(proof_out + A1, 0, A2 * 8);
+    if (H1::is_inf(krs)) memset(proof_out + A1 + A2, 0, A1 * 8);
+}
+
+// witness: m x EW/2 uint64 gnark Montgomery words (host, or device with flags & 1); r_mont/s_mont: the blinding
+// factors gnark draws from crypto/rand, injected so results are reproducible.  proof_out: Ar | Bs | Krs as affine
+// Montgomery images exactly as gnark's Proof holds them (G1Affine, G2Affine, G1Affine of the curve).
+template <class SU> static int32_t groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
+                                                 const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out) {
+    TRY(enter(ctx));
+    if (!pk || !witness || !r_mont || !s_mont || !proof_out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    if (pk->suite != SU::SUITE) return fail(DVN_ERR_INVALID_ARG, "proving key belongs to another curve");
+    const HostKey<SU>& hk = *(const HostKey<SU>*)pk->hk;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    Blind<SU> bl(hk, r_mont, s_mont);
+    MsmResults<SU> R;
+    TRY(groth16_device<SU>(ctx, pk, witness, flags, 0, 1, &R));
+    groth16_assemble<SU>(hk, R, bl, proof_out);
+    return DVN_OK;
+}
+
+// ---- sharded proving: rank `rank` of `world` computes its rows of the five MSMs; the partial results travel as Jacobian
+// images (affine normal form, Z = 1 or 0): A | B1 | K | Z (3 x fp words each) | B2 (3 x G2 coordinate words) ----------------
+template <class SU> struct PartialLayout {
+    static constexpr size_t J1 = SU::G1T::AW / 2 * 3 / 2, J2 = SU::G2T::AW / 2 * 3 / 2;     // uint64 words of a G1 / G2 Jacobian image
+    static constexpr size_t WORDS = 4 * J1 + J2;
+};
+template <class SU> static int32_t groth16_prove_shard(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
+                                                       uint32_t rank, uint32_t world, uint64_t* partial_out) {
+    typedef typename SU::H1 H1;
+    typedef typename SU::H2 H2;
+    TRY(enter(ctx));
+    if (!pk || !witness || !partial_out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    if (pk->suite != SU::SUITE) return fail(DVN_ERR_INVALID_ARG, "proving key belongs to another curve");
+    if (world < 1 || world > 64 || rank >= world) return fail(DVN_ERR_INVALID_ARG, "rank %u outside world %u", rank, world);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    MsmResults<SU> R;
+    TRY(groth16_device<SU>(ctx, pk, witness, flags, rank, world, &R));
+    constexpr size_t J1 = PartialLayout<SU>::J1;
+    H1::write_jac(R.mA, partial_out); H1::write_jac(R.mB, partial_out + J1); H1::write_jac(R.mK, partial_out + 2 * J1);
+    H1::write_jac(R.mZ, partial_out + 3 * J1); H2::write_jac(R.mB2, partial_out + 4 * J1);
+    return DVN_OK;
+}
+// host only: partials = world x PartialLayout::WORDS as gathered from the ranks
+template <class SU> static int32_t groth16_prove_combine(const dvn_groth16_pk* pk, const uint64_t* partials, uint32_t world,
+                                                         const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out) {
+    typedef typename SU::G1T G1;
+    typedef typename SU::G2T G2;
+    typedef typename SU::H1 H1;
+    typedef typename SU::H2 H2;
+    if (!pk || !partials || !r_mont || !s_mont || !proof_out || world < 1) return fail(DVN_ERR_INVALID_ARG, "bad argument");
+    if (pk->suite != SU::SUITE) return fail(DVN_ERR_INVALID_ARG, "proving key belongs to another curve");
+    const HostKey<SU>& hk = *(const HostKey<SU>*)pk->hk;
+    Blind<SU> bl(hk, r_mont, s_mont);
+    auto rd1 = [](const uint64_t* j) -> typename H1::X {
+        const u32* w = (const u32*)j; bool z = true;
+        for (int i = 0; i < G1::AW / 2; ++i) z = z && w[G1::AW + i] == 0;                  // Z == 0: infinity
+        if (z) return H1::infinity();
+        u32 img[G1::AW]; G1::store_affine_internal(G1::affine_from_ext(w), img);
+        return H1::load_device_affine(img);
+    };
+    auto rd2 = [](const uint64_t* j) -> typename H2::X {
+        const u32* w = (const u32*)j; bool z = true;
+        for (int i = 0; i < G2::AW / 2; ++i) z = z && w[G2::AW + i] == 0;
+        if (z) return H2::infinity();
+        u32 img[G2::AW]; G2::store_affine_internal(G2::affine_from_ext(w), img);
+        return H2::load_device_affine(img);
+    };
+    constexpr size_t J1 = PartialLayout<SU>::J1, PW = PartialLayout<SU>::WORDS;
+    MsmResults<SU> R{H1::infinity(), H1::infinity(), H1::infinity(), H1::infinity(), H2::infinity()};
+    for (uint32_t k = 0; k < world; ++k) {
+        const uint64_t* p = partials + (size_t)k * PW;
+        R.mA = H1::add(R.mA, rd1(p)); R.mB = H1::add(R.mB, rd1(p + J1)); R.mK = H1::add(R.mK, rd1(p + 2 * J1));
+        R.mZ = H1::add(R.mZ, rd1(p + 3 * J1)); R.mB2 = H2::add(R.mB2, rd2(p + 4 * J1));
+    }
+    groth16_assemble<SU>(hk, R, bl, proof_out);
+    return DVN_OK;
 }

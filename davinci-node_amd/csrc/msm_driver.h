@@ -558,6 +558,22 @@ static int32_t msm_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_
     *lane_out = L;
     return DVN_OK;
 }
+// rows [row_lo, row_hi) of an EXPANDED set (device scalars): ONE partial result, window weights included; the partial
+// results of disjoint row ranges add up to the MSM (this is what a rank of the sharded Groth16 prover computes)
+template <class Cv>
+static int32_t msm_rows_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, u32 row_lo, u32 row_hi, MsmLane** lane_out) {
+    if (off > pts->n || n > pts->n - off) return fail(DVN_ERR_INVALID_ARG, "len(points) != len(scalars): range [%zu, %zu) outside point set of %zu", off, off + n, pts->n);
+    if (n && !use_expanded(pts, n)) return fail(DVN_ERR_UNSUPPORTED, "row-sharded MSM needs an expanded point set (n >= 2^15 points, most of the set)");
+    if (row_lo > row_hi || (n && row_hi > pts->nexp)) return fail(DVN_ERR_INVALID_ARG, "row range [%u, %u) outside [0, %u)", row_lo, row_hi, pts->nexp);
+    MsmLane* L = nullptr;
+    TRY(lane_acquire(ctx, &L));
+    L->curve = pts->curve; L->W = 0; L->expanded = true; L->c = 0;
+    L->nwin = (n && row_hi > row_lo) ? 1 : 0;
+    int32_t rc = L->nwin ? msm_expanded<Cv>(ctx, *L, pts, off, n, (const uint64_t*)d_scalars, DVN_MSM_SCALARS_ON_DEVICE, row_lo, row_hi) : DVN_OK;
+    if (rc != DVN_OK) { (void)hipStreamSynchronize(L->stream); L->busy = false; return rc; }
+    *lane_out = L;
+    return DVN_OK;
+}
 // complete it: host-side window combine (host_fast.h)
 template <class Cv>
 static int32_t msm_collect(dvn_ctx* ctx, MsmLane& L, typename FastHost<Cv>::G::X* out) {

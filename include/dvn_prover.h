@@ -157,6 +157,15 @@ int32_t dvn_groth16_pk_free(dvn_ctx* ctx, dvn_groth16_pk* pk);
  * proof_out: Ar (8) | Bs (16) | Krs (8) uint64 = groth16_bn254.Proof{Ar, Bs, Krs} affine images. */
 int32_t dvn_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
                           const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32]);
+/* Sharded proving (BASELINE.json config 5: the statetransition proof's MSMs sharded across the GPUs of one node).  Every rank
+ * holds the whole key and witness; rank `rank` of `world` runs the "solve" and computeH and ITS ROWS of the five MSMs
+ * (dvn_groth16_prove_shard: 72 uint64 of partial results -- Jacobian images of A, B1, K, Z partial sums, 12 each, and of B2,
+ * 24), the ranks all-gather the 576-byte buffers (RCCL), and dvn_groth16_prove_combine (host only) adds the partial results
+ * and assembles the proof.  The key's point sets must be expanded (>= 2^15 points each; DVN_ERR_UNSUPPORTED otherwise). */
+int32_t dvn_groth16_prove_shard(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
+                                uint32_t rank, uint32_t world, uint64_t partial_out[72]);
+int32_t dvn_groth16_prove_combine(const dvn_groth16_pk* pk, const uint64_t* partials /* world x 72 */, uint32_t world,
+                                  const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32]);
 /* device time of the last prove call (any curve): ms_h = start until h is ready on the main stream (witness copy, gathers,
  * "solve", computeH -- the B2, A, B1 and K MSMs already run beside it on the four lanes), ms_msm = from there to the last MSM, total */
 int32_t dvn_groth16_last_ms(const dvn_groth16_pk* pk, float* ms_h, float* ms_msm, float* ms_total);

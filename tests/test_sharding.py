@@ -31,7 +31,10 @@ def _worker(rank, world, port, n, c, q):
     assert rc == 0
     got = orc.g1_jac_to_affine(out)
     want = orc.msm_g1(pts, sc)
-    q.put((rank, bool((got == want).all())))
+    # the fixed-size row all-gather of the sharded Groth16 prover (72 uint64 of partial results per rank)
+    rows = sharding.all_gather_rows(np.arange(72, dtype=np.uint64) + 1000 * rank, world, dist, "cpu")
+    rows_ok = rows.shape == (world, 72) and all((rows[r] == np.arange(72, dtype=np.uint64) + 1000 * r).all() for r in range(world))
+    q.put((rank, bool((got == want).all()) and rows_ok))
     dist.barrier()
     dist.destroy_process_group()
 
