@@ -155,7 +155,7 @@ template <class Cv> static u32 pick_segment(size_t total) {
         else { (void)hipGetLastError(); slots = 196608; }
     }
     static const int forced = []() { const char* v = getenv("DVN_MSM_SEG"); return v ? atoi(v) : 0; }();
-    if (forced >= 16) return (u32)forced;
+    if (forced >= 2) return (u32)forced;
     size_t seg = total / (slots * 4);
     if (seg < 16) seg = 16;
     if (seg > 128) seg = 128;
