@@ -118,6 +118,12 @@ def load_library():
         "dvn_bls12381_r1cs_synthetic": (i32, [u64, u32, u32, C.POINTER(vp)]),
         "dvn_bls12381_groth16_setup": (i32, [vp, vp, u64, C.POINTER(vp)]),
         "dvn_bls12381_groth16_prove": (i32, [vp, vp, vp, u32, vp, vp, vp]),
+        "dvn_kzg_setup_load": (i32, [vp, vp, vp, C.POINTER(vp)]),
+        "dvn_kzg_setup_free": (i32, [vp, vp]),
+        "dvn_kzg_blob_to_commitment": (i32, [vp, vp, vp, vp]),
+        "dvn_kzg_compute_proof": (i32, [vp, vp, vp, vp, vp, vp]),
+        "dvn_kzg_compute_cell_proofs": (i32, [vp, vp, vp, vp]),
+        "dvn_kzg_evaluate_barycentric": (i32, [vp, vp, vp, vp, vp]),
         "dvn_r1cs_curve": (i32, [vp]),
         "dvn_bw6761_points_upload": (i32, [vp, C.c_int, vp, sz, C.POINTER(vp)]),
         "dvn_bw6761_points_synthetic": (i32, [vp, C.c_int, vp, u64, sz, C.POINTER(vp)]),
@@ -161,6 +167,8 @@ EXPORTED_SYMBOLS = [
     "dvn_bls12381_points_upload_g1", "dvn_bls12381_points_upload_g2", "dvn_bls12381_points_synthetic_g1", "dvn_bls12381_points_download",
     "dvn_bls12381_scalars_synthetic", "dvn_bls12381_msm_g1", "dvn_bls12381_msm_g2", "dvn_bls12381_ntt_domain", "dvn_bls12381_ntt", "dvn_bls12381_groth16_compute_h",
     "dvn_bls12381_r1cs_synthetic", "dvn_bls12381_groth16_setup", "dvn_bls12381_groth16_prove", "dvn_r1cs_curve",
+    "dvn_kzg_setup_load", "dvn_kzg_setup_free", "dvn_kzg_blob_to_commitment", "dvn_kzg_compute_proof", "dvn_kzg_compute_cell_proofs",
+    "dvn_kzg_evaluate_barycentric",
     "dvn_bw6761_points_upload", "dvn_bw6761_points_synthetic", "dvn_bw6761_points_download", "dvn_bw6761_scalars_synthetic", "dvn_bw6761_msm",
     "dvn_bw6761_ntt_domain", "dvn_bw6761_ntt", "dvn_bw6761_groth16_compute_h",
     "dvn_bw6761_r1cs_synthetic", "dvn_bw6761_groth16_setup", "dvn_bw6761_groth16_prove",
@@ -604,3 +612,67 @@ class Bw6761:
         out = np.zeros((dom.n, 6), dtype=np.uint64)
         self.ctx._chk(self.L.dvn_bw6761_groth16_compute_h(self.ctx.h, dom.handle, _host(a), _host(b), _host(c), a.shape[0], _host(out), 0))
         return out
+
+
+class KzgSetup:
+    """Device-resident EIP-4844 trusted setup + the blob operations of the reference's types.Blob
+    (/root/reference/types/blobs.go:88-133), same names and byte formats:
+      compute_commitment(blob) -> 48 bytes            Blob.ComputeCommitment
+      compute_proof(blob, z)   -> (48 bytes, y: int)  Blob.ComputeProof (z: int; error if it does not fit the field)
+      compute_cell_proofs(blob) -> list of 128 x 48 bytes   Blob.ComputeCellProofs
+      evaluate_barycentric(blob, z) -> int            crypto/blobs/barycentric.go EvaluateBarycentricNative
+    g1_lagrange / g1_monomial: 4096 x 48-byte compressed points in the order of config/kzg_trusted_setup.txt."""
+    BLOB_BYTES = 131072
+
+    def __init__(self, ctx: "Context", g1_lagrange: bytes, g1_monomial: bytes = None):
+        if len(g1_lagrange) != 4096 * 48 or (g1_monomial is not None and len(g1_monomial) != 4096 * 48):
+            raise ValueError("trusted setup bases must be 4096 x 48 bytes")
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx._chk(ctx.L.dvn_kzg_setup_load(ctx.h, g1_lagrange, g1_monomial, C.byref(h)))
+        self.h = h
+
+    @classmethod
+    def from_file(cls, ctx: "Context", path: str):
+        """Text format of config/kzg_trusted_setup.txt: n1, n2, n1 G1 Lagrange, n2 G2 monomial, n1 G1 monomial (hex lines)."""
+        t = open(path).read().split()
+        n1, n2 = int(t[0]), int(t[1])
+        lag = bytes.fromhex("".join(t[2:2 + n1]))
+        mono = bytes.fromhex("".join(t[2 + n1 + n2:2 + 2 * n1 + n2])) if len(t) >= 2 + 2 * n1 + n2 else None
+        return cls(ctx, lag, mono)
+
+    def close(self):
+        if self.h:
+            self.ctx._chk(self.ctx.L.dvn_kzg_setup_free(self.ctx.h, self.h))
+            self.h = None
+
+    def _blob(self, blob: bytes) -> bytes:
+        if len(blob) != self.BLOB_BYTES:
+            raise ValueError("blob length is %d, want 131072" % len(blob))
+        return bytes(blob)
+
+    @staticmethod
+    def _point(z: int) -> bytes:
+        if z < 0 or z.bit_length() > 256:
+            raise ValueError("point does not fit in 32 bytes")              # types/blobs.go:122-124
+        return z.to_bytes(32, "big")
+
+    def compute_commitment(self, blob: bytes) -> bytes:
+        out = C.create_string_buffer(48)
+        self.ctx._chk(self.ctx.L.dvn_kzg_blob_to_commitment(self.ctx.h, self.h, self._blob(blob), out))
+        return out.raw
+
+    def compute_proof(self, blob: bytes, z: int):
+        proof, y = C.create_string_buffer(48), C.create_string_buffer(32)
+        self.ctx._chk(self.ctx.L.dvn_kzg_compute_proof(self.ctx.h, self.h, self._blob(blob), self._point(z), proof, y))
+        return proof.raw, int.from_bytes(y.raw, "big")
+
+    def compute_cell_proofs(self, blob: bytes):
+        out = C.create_string_buffer(128 * 48)
+        self.ctx._chk(self.ctx.L.dvn_kzg_compute_cell_proofs(self.ctx.h, self.h, self._blob(blob), out))
+        return [out.raw[48 * k:48 * k + 48] for k in range(128)]
+
+    def evaluate_barycentric(self, blob: bytes, z: int) -> int:
+        y = C.create_string_buffer(32)
+        self.ctx._chk(self.ctx.L.dvn_kzg_evaluate_barycentric(self.ctx.h, self.h, self._blob(blob), self._point(z), y))
+        return int.from_bytes(y.raw, "big")

@@ -79,3 +79,6 @@ extern "C" int32_t dvn_bls12381_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, 
                                               const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[48]) {
     return groth16_prove<SuiteBls12381>(ctx, pk, witness, flags, r_mont, s_mont, proof_out);
 }
+
+// ---- blob KZG (EIP-4844 / EIP-7594) on this curve: SURVEY.md row f3 ----------------------------------------------------
+#include "kzg_impl.h"

@@ -1,0 +1,445 @@
+// EIP-4844 / EIP-7594 blob KZG on the device -- the step right before every state-transition proof:
+//   Blob.ComputeCommitment      /root/reference/types/blobs.go:88-95     (gethkzg.BlobToCommitment)
+//   Blob.ComputeProof(z)        /root/reference/types/blobs.go:120-133   (gethkzg.ComputeProof -> proof, claim)
+//   Blob.ComputeCellProofs      /root/reference/types/blobs.go:97-104    (gethkzg.ComputeCellProofs, 128 proofs)
+//   EvaluateBarycentricNative   /root/reference/crypto/blobs/barycentric.go:24-170
+// called from BlobEvalData.Set (/root/reference/crypto/blobs/blob.go:40-90).  Included by dvn_bls12381.hip so the MSM
+// kernels of G1_381 are instantiated once.
+//
+// MI355X-first shape: the setup is decompressed ON the device (one square root per thread) and stays resident; a blob costs
+// one 128 KiB upload; the quotient of compute_proof is one single-block kernel (batch inversion per thread, LDS tree sums);
+// the 128 cell proofs are ONE batched MSM -- 128 quotient polynomials (synthetic division by X^64 - h_k^64, one thread per
+// (cell, residue class)) committed over the same 4032 monomial points, every (cell, window) pair a virtual window of one
+// sorted entry list -- instead of FK20's Toeplitz/EC-FFT pipeline: KZG proofs are unique group elements, the bytes are the
+// same.  Window combine, affine normalisation and ZCash compression run on the device; 48 bytes per point come back.
+#pragma once
+#include "suite_api.h"
+
+namespace kzg {
+constexpr u32 N = 4096, LOGN = 12, CELLS = 128, CELL = 64, QN = N - CELL;     // QN = coefficients of a cell quotient
+typedef Fr381Cfg S;
+typedef Fp381Cfg B;
+typedef Fe<S> Fr;
+typedef Fe<B> Fq;
+typedef G1_381 Cv;
+constexpr int SW = S::EW, BW = B::EW;       // 8 / 12 u32 words
+
+enum : u32 { ERR_ENCODING = 1, ERR_NOT_ON_CURVE = 2, ERR_NON_CANONICAL = 4 };
+
+__device__ __forceinline__ u32 bitrev(u32 i, u32 bits) { return __brev(i) >> (32 - bits); }
+template <class C> __device__ __forceinline__ bool is_canonical_int(const Fe<C>& x) {      // integer limbs: x < modulus
+    const Fe<C> c = fe_canonical<C>(x);
+    u32 d = 0;
+#pragma unroll
+    for (int i = 0; i < C::NL; ++i) d |= c.v[i] ^ x.v[i];
+    return d == 0;
+}
+template <class C> __device__ __forceinline__ Fe<C> to_integer(const Fe<C>& a) { return fe_canonical<C>(fe_mul<C>(a, fe_small<C>(1))); }   // internal -> canonical integer limbs
+template <class C> __device__ __forceinline__ Fe<C> pow_bits(const Fe<C>& a, u32 e, int bits) {
+    Fe<C> acc = fe_one<C>();
+    for (int i = bits - 1; i >= 0; --i) { acc = fe_sqr<C>(acc); if ((e >> i) & 1) acc = fe_mul<C>(acc, a); }
+    return acc;
+}
+// big-endian bytes -> little-endian u32 words
+template <int W> __device__ __forceinline__ void be_to_words(const uint8_t* b, u32 (&w)[W]) {
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        const uint8_t* p = b + 4 * (W - 1 - i);
+        w[i] = ((u32)p[0] << 24) | ((u32)p[1] << 16) | ((u32)p[2] << 8) | (u32)p[3];
+    }
+}
+template <int W> __device__ __forceinline__ void words_to_be(const u32 (&w)[W], uint8_t* b) {
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        uint8_t* p = b + 4 * (W - 1 - i);
+        p[0] = (uint8_t)(w[i] >> 24); p[1] = (uint8_t)(w[i] >> 16); p[2] = (uint8_t)(w[i] >> 8); p[3] = (uint8_t)w[i];
+    }
+}
+// y > (p - 1)/2  <=>  2y > p (p odd), y a canonical integer
+__device__ __forceinline__ bool lexicographically_largest(const Fq& y) {
+    i32 d[B::NL];
+#pragma unroll
+    for (int i = 0; i < B::NL; ++i) d[i] = (i32)(2 * y.v[i]) - (i32)B::p(i);
+    fe_carry<B>(d);
+    return d[B::NL - 1] >= 0;
+}
+
+// ---- setup: 48-byte ZCash-compressed G1 -> internal affine image (optionally at the bit-reversed position) --------------
+// No subgroup check (the setup is the trusted ceremony output; the reference loads its proving keys with UnsafeReadFrom too,
+// /root/reference/circuits/artifacts.go:391-406).
+static __global__ void k_g1_decompress(const uint8_t* __restrict__ in, u32* __restrict__ pts, u32 n, u32 brp_bits, u32* __restrict__ err) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* b = in + (size_t)48 * i;
+    const u32 dst = brp_bits ? bitrev(i, brp_bits) : i;
+    u32* out = pts + (size_t)dst * Cv::AW;
+    const uint8_t flags = b[0];
+    u32 w[BW];
+    be_to_words<BW>(b, w);
+    w[BW - 1] &= 0x1fffffffu;
+    if (!(flags & 0x80)) { atomicOr(err, (u32)ERR_ENCODING); return; }
+    if (flags & 0x40) {
+        u32 any = (flags & 0x20) ? 1u : 0u;
+#pragma unroll
+        for (int k = 0; k < BW; ++k) any |= w[k];
+        if (any) atomicOr(err, (u32)ERR_ENCODING);
+        for (int k = 0; k < Cv::AW; ++k) out[k] = 0;               // affine infinity = all-zero image
+        return;
+    }
+    const Fq xi = fe_unpack<B>(w);
+    if (!is_canonical_int<B>(xi)) { atomicOr(err, (u32)ERR_ENCODING); return; }
+    const Fq x = fe_from_canonical<B>(xi);
+    const Fq one = fe_one<B>(), two = fe_add<B>(one, one), four = fe_add<B>(two, two);
+    const Fq y2 = fe_add<B>(fe_mul<B>(fe_sqr<B>(x), x), four);
+    // sqrt: y2^((p+1)/4), p = 3 mod 4; exponent limbs built from the modulus table like fe_inv's
+    Fq y = one;
+    {
+        u32 e[B::NL];                                                // (p + 1) >> 2 as 29-bit limbs
+        u32 carry = 1;
+#pragma unroll
+        for (int k = 0; k < B::NL; ++k) { const u32 t = B::p(k) + carry; e[k] = t & LMASK; carry = t >> LB; }
+#pragma unroll
+        for (int k = 0; k < B::NL; ++k) e[k] = (e[k] >> 2) | (k + 1 < B::NL ? (e[k + 1 < B::NL ? k + 1 : 0] & 3u) << (LB - 2) : 0u);
+        for (int k = B::NL - 1; k >= 0; --k) {
+            u32 limb = 0;
+#pragma unroll
+            for (int j = 0; j < B::NL; ++j) limb = (j == k) ? e[j] : limb;
+            for (int bt = LB - 1; bt >= 0; --bt) { y = fe_sqr<B>(y); if ((limb >> bt) & 1) y = fe_mul<B>(y, y2); }
+        }
+    }
+    if (!fe_eq<B>(fe_sqr<B>(y), y2)) { atomicOr(err, (u32)ERR_NOT_ON_CURVE); return; }
+    if (lexicographically_largest(to_integer<B>(y)) != (bool)(flags & 0x20)) y = fe_neg<B>(y);
+    u32 o[Cv::AW];
+    Cv::store_affine_internal(Cv::A{x, y}, o);
+    store_words16(out, o, Cv::AW);
+}
+
+// ---- blob: 4096 x 32 big-endian bytes -> scalar images (x * 2^256 mod r, what the MSM and NTT entry points consume) ------
+static __global__ void k_blob_scalars(const uint8_t* __restrict__ blob, u32* __restrict__ f_ext, u32* __restrict__ err) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    u32 w[SW];
+    be_to_words<SW>(blob + (size_t)32 * i, w);
+    const Fr xi = fe_unpack<S>(w);
+    if (!is_canonical_int<S>(xi) || (w[SW - 1] >> 31)) atomicOr(err, (u32)ERR_NON_CANONICAL);     // EIP-4844 bytes_to_bls_field
+    u32 o[SW];
+    fe_to_ext_mont<S>(fe_from_canonical<S>(xi), o);
+    store_words16(f_ext + (size_t)i * SW, o, SW);
+}
+
+// LDS tree sum of one field element per thread (blockDim = 1024); every thread gets the total
+__device__ __forceinline__ Fr block_sum_fr(Fr v, u32* sh) {
+    const u32 t = threadIdx.x;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < S::NL; ++k) sh[k * 1024 + t] = v.v[k];
+    __syncthreads();
+    for (u32 s = 512; s >= 1; s >>= 1) {
+        if (t < s) {
+            Fr a, c;
+#pragma unroll
+            for (int k = 0; k < S::NL; ++k) { a.v[k] = sh[k * 1024 + t]; c.v[k] = sh[k * 1024 + t + s]; }
+            a = fe_add<S>(a, c);
+#pragma unroll
+            for (int k = 0; k < S::NL; ++k) sh[k * 1024 + t] = a.v[k];
+        }
+        __syncthreads();
+    }
+    Fr r;
+#pragma unroll
+    for (int k = 0; k < S::NL; ++k) r.v[k] = sh[k * 1024];
+    return r;
+}
+
+// ---- compute_kzg_proof_impl's field part (EIP-4844), one block of 1024 threads x 4 elements:
+//   y = f(z) by the barycentric formula of crypto/blobs/barycentric.go:24-170 (or f_m when z = w_m, :99-107),
+//   q_i = (f_i - y) / (w_i - z), and compute_quotient_eval_within_domain for i = m.
+// z_int: canonical little-endian words.  consts: w_4096 (internal).  out_y: canonical integer words of y.
+static __global__ __launch_bounds__(1024) void k_kzg_quotient(const u32* __restrict__ f_ext, const u32* __restrict__ z_int, const u32* __restrict__ consts,
+                                                              u32* __restrict__ q_ext, u32* __restrict__ out_y) {
+    __shared__ u32 sh[S::NL * 1024];
+    __shared__ int s_m;
+    const u32 t = threadIdx.x;
+    if (t == 0) s_m = -1;
+    u32 zw[SW], cw[SW];
+#pragma unroll
+    for (int k = 0; k < SW; ++k) { zw[k] = z_int[k]; cw[k] = consts[k]; }
+    const Fr z = fe_from_canonical<S>(fe_unpack<S>(zw));
+    const Fr w1 = fe_unpack<S>(cw);                                   // stored internal (fr_store_internal)
+    __syncthreads();
+    Fr f[4], om[4], d[4];
+    bool hit[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const u32 i = t + 1024 * e;
+        u32 w[SW];
+        load_words16(f_ext + (size_t)i * SW, w, SW);
+        f[e] = fe_from_ext_mont<S>(w);
+        om[e] = pow_bits<S>(w1, bitrev(i, LOGN), LOGN);
+        d[e] = fe_sub<S>(z, om[e]);
+        hit[e] = fe_is_zero<S>(d[e]);
+        if (hit[e]) { s_m = (int)i; d[e] = fe_one<S>(); }
+    }
+    // 1 / (z - w_i): four per thread with one inversion
+    Fr inv[4];
+    {
+        const Fr p1 = fe_mul<S>(d[0], d[1]), p2 = fe_mul<S>(p1, d[2]), p3 = fe_mul<S>(p2, d[3]);
+        Fr a = fe_inv<S>(p3);
+        inv[3] = fe_mul<S>(a, p2); a = fe_mul<S>(a, d[3]);
+        inv[2] = fe_mul<S>(a, p1); a = fe_mul<S>(a, d[2]);
+        inv[1] = fe_mul<S>(a, d[0]); inv[0] = fe_mul<S>(a, d[1]);
+    }
+    __syncthreads();
+    const int m = s_m;
+    Fr y;
+    if (m < 0) {
+        Fr acc = fe_zero<S>();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = fe_add<S>(acc, fe_mul<S>(fe_mul<S>(f[e], om[e]), inv[e]));
+        const Fr sum = block_sum_fr(acc, sh);
+        // (z^4096 - 1) / 4096
+        Fr zp = z;
+        for (u32 k = 0; k < LOGN; ++k) zp = fe_sqr<S>(zp);
+        u32 nw[SW] = {N, 0, 0, 0, 0, 0, 0, 0};
+        const Fr ninv = fe_inv<S>(fe_from_canonical<S>(fe_unpack<S>(nw)));
+        y = fe_mul<S>(sum, fe_mul<S>(fe_sub<S>(zp, fe_one<S>()), ninv));
+    } else {
+        Fr mine = fe_zero<S>();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (hit[e]) mine = f[e];
+        y = block_sum_fr(mine, sh);                                   // exactly one non-zero term: f_m
+    }
+    Fr q[4], acc2 = fe_zero<S>();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const Fr g = fe_mul<S>(fe_sub<S>(f[e], y), inv[e]);           // (f_i - y) / (z - w_i)
+        q[e] = fe_neg<S>(g);
+        if (!hit[e]) acc2 = fe_add<S>(acc2, fe_mul<S>(g, om[e]));
+    }
+    if (m >= 0) {                                                     // q_m = sum_{i != m} (f_i - y) w_i / (z (z - w_i))
+        const Fr u = block_sum_fr(acc2, sh);
+        const Fr qm = fe_mul<S>(u, fe_inv<S>(z));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (hit[e]) q[e] = qm;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        u32 o[SW];
+        fe_to_ext_mont<S>(q[e], o);
+        store_words16(q_ext + (size_t)(t + 1024 * e) * SW, o, SW);
+    }
+    if (t == 0) {
+        u32 o[SW];
+        fe_pack<S>(to_integer<S>(y), o);
+#pragma unroll
+        for (int k = 0; k < SW; ++k) out_y[k] = o[k];
+    }
+}
+
+// ---- cell quotients: q_k(X) = (f(X) - I_k(X)) / (X^64 - c_k), c_k = h_k^64 = w_128^bitrev7(k) (EIP-7594 coset_for_cell);
+// thread (k, r) walks the residue class j = r mod 64 from the top: q_k[j] = f[j + 64] + c_k q_k[j + 64].
+// coef_ext: the blob's monomial coefficients (scalar images); consts + SW: w_128 (internal); q_ext: CELLS x QN scalar images.
+static __global__ void k_cell_quotients(const u32* __restrict__ coef_ext, const u32* __restrict__ consts, u32* __restrict__ q_ext) {
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= CELLS * CELL) return;
+    const u32 k = g / CELL, r = g % CELL;
+    u32 cw[SW];
+#pragma unroll
+    for (int i = 0; i < SW; ++i) cw[i] = consts[SW + i];
+    const Fr c = pow_bits<S>(fe_unpack<S>(cw), bitrev(k, 7), 7);
+    Fr acc = fe_zero<S>();
+    for (int m = (int)(QN / CELL) - 1; m >= 0; --m) {
+        const u32 j = r + CELL * (u32)m;
+        u32 w[SW];
+        load_words16(coef_ext + (size_t)(j + CELL) * SW, w, SW);
+        acc = fe_add<S>(fe_from_ext_mont<S>(w), fe_mul<S>(c, acc));
+        u32 o[SW];
+        fe_to_ext_mont<S>(acc, o);
+        store_words16(q_ext + ((size_t)k * QN + j) * SW, o, SW);
+    }
+}
+
+// ---- result points: internal xyzz -> 48-byte ZCash-compressed G1 (what KZGCommitment / KZGProof hold, types/blobs.go:165,199)
+static __global__ void k_g1_compress(const u32* __restrict__ xyzz, u32 n, uint8_t* __restrict__ out) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t* b = out + (size_t)48 * i;
+    const Cv::X p = ld_xyzz<Cv>(xyzz + (size_t)i * Cv::XW);
+    if (Cv::is_inf(p)) { b[0] = 0xC0; for (int k = 1; k < 48; ++k) b[k] = 0; return; }
+    const Cv::A a = Cv::to_affine(p);
+    u32 w[BW];
+    fe_pack<B>(to_integer<B>(a.x), w);
+    words_to_be<BW>(w, b);
+    b[0] |= 0x80 | (lexicographically_largest(to_integer<B>(a.y)) ? 0x20 : 0x00);
+}
+}  // namespace kzg
+
+struct dvn_kzg_setup {
+    dvn_points* lagrange_brp = nullptr;      // L_bitrev(i): basis point of the blob's i-th element
+    dvn_points* monomial = nullptr;          // [tau^j]G1 (cell proofs), may be NULL
+    dvn_domain* dom = nullptr;               // BLS12-381 Fr domain of 4096
+    uint8_t* d_bytes = nullptr;              // staging: blob (128 KiB) / compressed points in (192 KiB) / out (6 KiB)
+    u32 *d_f = nullptr, *d_q = nullptr, *d_cellq = nullptr, *d_res = nullptr, *d_small = nullptr;   // d_small: z, y, consts, err
+};
+
+static int32_t kzg_points_from_compressed(dvn_ctx* ctx, dvn_kzg_setup* s, const uint8_t* bytes48, u32 brp_bits, dvn_points** out) {
+    dvn_points* p = new (std::nothrow) dvn_points();
+    if (!p) return fail(DVN_ERR_OOM, "host allocation failed");
+    p->curve = 1; p->n = kzg::N; p->suite = SuiteOf<G1_381>::value; p->expand_c = 0; p->nexp = 1;
+    u32* err = s->d_small + 64;
+    hipError_t e = hipMalloc((void**)&p->d, (size_t)kzg::N * G1_381::AW * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->d_bytes, bytes48, (size_t)kzg::N * 48, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(err, 0, 4, ctx->stream);
+    u32 herr = 0;
+    if (e == hipSuccess) {
+        kzg::k_g1_decompress<<<kzg::N / 64, 64, 0, ctx->stream>>>(s->d_bytes, p->d, kzg::N, brp_bits, err);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess || herr) {
+        if (p->d) (void)hipFree(p->d);
+        delete p; (void)hipGetLastError();
+        if (e != hipSuccess) return fail(DVN_ERR_DEVICE, "setup decompression failed: %s", hipGetErrorString(e));
+        return fail(DVN_ERR_INVALID_ARG, "trusted setup: %s", (herr & kzg::ERR_NOT_ON_CURVE) ? "point is not on the curve" : "bad compressed G1 encoding");
+    }
+    *out = p;
+    return DVN_OK;
+}
+
+static void kzg_setup_destroy(dvn_kzg_setup* s) {            // no locking, no ctx: direct frees (caller synchronised)
+    if (!s) return;
+    for (dvn_points* p : {s->lagrange_brp, s->monomial}) if (p) { if (p->d) (void)hipFree(p->d); delete p; }
+    if (s->dom) {
+        dvn_domain* d = s->dom;
+        u32* ptrs[] = {d->tw_fwd, d->tw_inv, d->g_lo, d->g_hi, d->gi_lo, d->gi_hi, d->card_inv, d->h_consts};
+        for (u32* q : ptrs) if (q) (void)hipFree(q);
+        delete d;
+    }
+    void* bufs[] = {s->d_bytes, s->d_f, s->d_q, s->d_cellq, s->d_res, s->d_small};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    delete s;
+}
+extern "C" int32_t dvn_kzg_setup_free(dvn_ctx* ctx, dvn_kzg_setup* s) {
+    TRY(enter(ctx));
+    if (!s) return DVN_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipDeviceSynchronize();
+    kzg_setup_destroy(s);
+    return DVN_OK;
+}
+
+extern "C" int32_t dvn_kzg_setup_load(dvn_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t* g1_monomial, dvn_kzg_setup** out) {
+    TRY(enter(ctx));
+    if (!g1_lagrange || !out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    dvn_kzg_setup* s = new (std::nothrow) dvn_kzg_setup();
+    if (!s) return fail(DVN_ERR_OOM, "host allocation failed");
+    int32_t rc = ntt_domain_create<Fr381Cfg>(ctx, kzg::LOGN, &s->dom);           // takes ctx->mu itself
+    if (rc != DVN_OK) { kzg_setup_destroy(s); return rc; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto alloc = [&](void** p, size_t bytes) -> int32_t { HIP_TRY(hipMalloc(p, bytes)); return DVN_OK; };
+    if ((rc = alloc((void**)&s->d_bytes, (size_t)kzg::N * 48)) || (rc = alloc((void**)&s->d_f, (size_t)kzg::N * kzg::SW * 4)) ||
+        (rc = alloc((void**)&s->d_q, (size_t)kzg::N * kzg::SW * 4)) || (rc = alloc((void**)&s->d_res, (size_t)kzg::CELLS * G1_381::XW * 4)) ||
+        (rc = alloc((void**)&s->d_small, 512)) ||
+        (g1_monomial && (rc = alloc((void**)&s->d_cellq, (size_t)kzg::CELLS * kzg::QN * kzg::SW * 4)))) { kzg_setup_destroy(s); return rc; }
+    // constants: w_4096 and w_128 in internal form at d_small + 16 / + 24 (u32 words)
+    u32 h[2 * kzg::SW];
+    fr_store_internal<Fr381Cfg>(fr_root_of_unity<Fr381Cfg>(12), h);
+    fr_store_internal<Fr381Cfg>(fr_root_of_unity<Fr381Cfg>(7), h + kzg::SW);
+    hipError_t e = hipMemcpy(s->d_small + 16, h, sizeof(h), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { kzg_setup_destroy(s); (void)hipGetLastError(); return fail(DVN_ERR_DEVICE, "constant upload failed: %s", hipGetErrorString(e)); }
+    if ((rc = kzg_points_from_compressed(ctx, s, g1_lagrange, kzg::LOGN, &s->lagrange_brp)) ||
+        (g1_monomial && (rc = kzg_points_from_compressed(ctx, s, g1_monomial, 0, &s->monomial)))) { kzg_setup_destroy(s); return rc; }
+    *out = s;
+    return DVN_OK;
+}
+
+// blob bytes -> device scalar images in s->d_f (caller holds ctx->mu)
+static int32_t kzg_load_blob(dvn_ctx* ctx, const dvn_kzg_setup* s, const uint8_t* blob) {
+    u32* err = s->d_small + 64;
+    u32 herr = 0;
+    HIP_TRY(hipMemcpyAsync(s->d_bytes, blob, (size_t)kzg::N * 32, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(err, 0, 4, ctx->stream));
+    kzg::k_blob_scalars<<<kzg::N / 256, 256, 0, ctx->stream>>>(s->d_bytes, s->d_f, err);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (herr) return fail(DVN_ERR_INVALID_ARG, "blob element is not a canonical field element");
+    return DVN_OK;
+}
+// `batch` MSMs of n scalars each over pts[0, n) -> `batch` compressed points in out48 (caller holds ctx->mu)
+static int32_t kzg_commit(dvn_ctx* ctx, const dvn_kzg_setup* s, const dvn_points* pts, size_t n, const u32* d_scalars, u32 batch, uint8_t* out48) {
+    static const u32 c_single = []() { const char* v = getenv("DVN_KZG_C"); const int x = v ? atoi(v) : 0; return (u32)((x >= 4 && x <= 16) ? x : 0); }();
+    static const u32 c_cells = []() { const char* v = getenv("DVN_KZG_CELL_C"); const int x = v ? atoi(v) : 0; return (u32)((x >= 4 && x <= 16) ? x : 9); }();
+    u32 c = c_cells, nwin;
+    if (batch == 1) { msm_plan(n, &c, &nwin, Fr381Cfg::BITS); if (c_single) c = c_single; }
+    MsmLane* L = nullptr;
+    TRY(msm_batched_submit<G1_381>(ctx, pts, 0, n, d_scalars, batch, c, s->d_res, &L));
+    uint8_t* d_out = s->d_bytes + (size_t)kzg::N * 40;                 // tail of the staging buffer (6 KiB needed)
+    kzg::k_g1_compress<<<(batch + 63) / 64, 64, 0, L->stream>>>(s->d_res, batch, d_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out48, d_out, (size_t)batch * 48, hipMemcpyDeviceToHost, L->stream);
+    int32_t rc = lane_wait(ctx, *L);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(DVN_ERR_DEVICE, "compression failed: %s", hipGetErrorString(e)); }
+    return rc;
+}
+
+extern "C" int32_t dvn_kzg_blob_to_commitment(dvn_ctx* ctx, const dvn_kzg_setup* s, const uint8_t* blob, uint8_t out[48]) {
+    TRY(enter(ctx));
+    if (!s || !blob || !out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(kzg_load_blob(ctx, s, blob));
+    return kzg_commit(ctx, s, s->lagrange_brp, kzg::N, s->d_f, 1, out);
+}
+
+static int32_t kzg_scalar_from_be(const uint8_t z_be[32], u32 zw[8]) {
+    static const u32 R381[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
+    for (int i = 0; i < 8; ++i) { const uint8_t* p = z_be + 4 * (7 - i); zw[i] = ((u32)p[0] << 24) | ((u32)p[1] << 16) | ((u32)p[2] << 8) | (u32)p[3]; }
+    if (geq8(zw, R381)) return fail(DVN_ERR_INVALID_ARG, "evaluation point is not a canonical field element");
+    return DVN_OK;
+}
+// quotient evaluations into s->d_q, y (big-endian) into y_out (caller holds ctx->mu; blob already loaded)
+static int32_t kzg_quotient(dvn_ctx* ctx, const dvn_kzg_setup* s, const u32 zw[8], uint8_t y_out[32]) {
+    u32 yw[8];
+    HIP_TRY(hipMemcpyAsync(s->d_small, zw, 32, hipMemcpyHostToDevice, ctx->stream));
+    kzg::k_kzg_quotient<<<1, 1024, 0, ctx->stream>>>(s->d_f, s->d_small, s->d_small + 16, s->d_q, s->d_small + 8);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(yw, s->d_small + 8, 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 8; ++i) { uint8_t* p = y_out + 4 * (7 - i); p[0] = (uint8_t)(yw[i] >> 24); p[1] = (uint8_t)(yw[i] >> 16); p[2] = (uint8_t)(yw[i] >> 8); p[3] = (uint8_t)yw[i]; }
+    return DVN_OK;
+}
+
+extern "C" int32_t dvn_kzg_evaluate_barycentric(dvn_ctx* ctx, const dvn_kzg_setup* s, const uint8_t* blob, const uint8_t z[32], uint8_t y[32]) {
+    TRY(enter(ctx));
+    if (!s || !blob || !z || !y) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    u32 zw[8];
+    TRY(kzg_scalar_from_be(z, zw));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(kzg_load_blob(ctx, s, blob));
+    return kzg_quotient(ctx, s, zw, y);
+}
+
+extern "C" int32_t dvn_kzg_compute_proof(dvn_ctx* ctx, const dvn_kzg_setup* s, const uint8_t* blob, const uint8_t z[32], uint8_t proof[48], uint8_t y[32]) {
+    TRY(enter(ctx));
+    if (!s || !blob || !z || !proof || !y) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    u32 zw[8];
+    TRY(kzg_scalar_from_be(z, zw));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(kzg_load_blob(ctx, s, blob));
+    TRY(kzg_quotient(ctx, s, zw, y));
+    return kzg_commit(ctx, s, s->lagrange_brp, kzg::N, s->d_q, 1, proof);
+}
+
+extern "C" int32_t dvn_kzg_compute_cell_proofs(dvn_ctx* ctx, const dvn_kzg_setup* s, const uint8_t* blob, uint8_t* proofs /* 128 x 48 */) {
+    TRY(enter(ctx));
+    if (!s || !blob || !proofs) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    if (!s->monomial) return fail(DVN_ERR_INVALID_ARG, "setup was loaded without the monomial G1 basis: no cell proofs");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(kzg_load_blob(ctx, s, blob));
+    // monomial coefficients: the blob lists evaluations in bit-reversed order = the input order of FFTInverse(DIT)
+    TRY(ntt_device<Fr381Cfg>(ctx, s->dom, s->d_f, 1, DVN_DIT, 0));
+    kzg::k_cell_quotients<<<kzg::CELLS * kzg::CELL / 64, 64, 0, ctx->stream>>>(s->d_f, s->d_small + 16, s->d_cellq);
+    HIP_TRY(hipGetLastError());
+    return kzg_commit(ctx, s, s->monomial, kzg::QN, s->d_cellq, kzg::CELLS, proofs);
+}

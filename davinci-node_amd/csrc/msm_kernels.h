@@ -191,6 +191,41 @@ template <class S> __global__ void k_digits16(const u32* __restrict__ scalars, s
     }
 }
 
+// Batched layout (B scalar vectors over ONE point set, msm_driver.h msm_windows_staged(batch > 1)): scalar s = b * n + i,
+// every (vector, window) pair is its own virtual window: digits[((b * nwin + win) * n + i], nwin = all windows of a scalar.
+template <class S> __global__ void k_digits16_batched(const u32* __restrict__ scalars, size_t n, u32 batch, u32 c, u32 nwin,
+                                                      int16_t* __restrict__ digits) {
+    constexpr int EW = S::EW;
+    size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n * batch) return;
+    const size_t b = s / n, i = s % n;
+    u32 w[EW];
+    load_words16(scalars + s * EW, w, EW);
+    Fe<S> k = fe_ext_mont_to_canonical<S>(w);
+    u32 kw[EW + 1];
+    {
+        u32 t[EW]; fe_pack<S>(k, t);
+#pragma unroll
+        for (int j = 0; j < EW; ++j) kw[j] = t[j];
+        kw[EW] = 0;
+    }
+    const u32 nb = 1u << (c - 1), mask = (1u << c) - 1;
+    u32 carry = 0;
+    for (u32 win = 0; win < nwin; ++win) {
+        const u32 bit = win * c;
+        u32 d = carry;
+        if (bit < 32 * EW) {
+            const u32 wi = bit >> 5, sh = bit & 31;
+            u64 two = (u64)kw[wi] | ((u64)kw[wi + 1] << 32);
+            d += (u32)(two >> sh) & mask;
+        }
+        carry = 0;
+        int v = (int)d;
+        if (d >= nb) { v = (int)d - (int)(1u << c); carry = 1; }
+        digits[((size_t)b * nwin + win) * n + i] = (int16_t)v;
+    }
+}
+
 // ====================================================================================================================
 // Expanded point sets ("one bucket set").  HBM is 288 GB, a proving key a few GB: at upload the table
 // is widened to rows  row_w[i] = 2^(c w) * P_i,  w < nexp.  Every window of every scalar then lands in the SAME
@@ -684,6 +719,22 @@ __global__ __launch_bounds__(64 * Lanes<Cv>::LPP) void k_window_finalize(const u
     acc = block_sum<Cv>(acc, sh);
     if (ltid<Cv>() == 0) st_xyzz<Cv>(acc, window_sums + (size_t)w * Cv::XW);
     (void)nwin_local;
+}
+
+// Batched MSM tail: one thread per scalar vector combines its nwin window sums MSB first (gnark's
+// `for j = last..0: acc = 2^c acc + W_j`) on the device -- with B results the sequential chain is no longer worth a
+// round trip to the host per result.  out: B internal xyzz images.
+template <class Cv>
+__global__ void k_batch_horner(const u32* __restrict__ window_sums, u32 nwin, u32 c, u32 batch, u32* __restrict__ out) {
+    typedef typename Cv::X X;
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    X acc = Cv::infinity();
+    for (int w = (int)nwin - 1; w >= 0; --w) {
+        for (u32 k = 0; k < c; ++k) acc = Cv::dbl(acc);
+        acc = Cv::add(acc, ld_xyzz<Cv>(window_sums + ((size_t)b * nwin + w) * Cv::XW));
+    }
+    st_xyzz<Cv>(acc, out + (size_t)b * Cv::XW);
 }
 
 }  // namespace dvn

@@ -292,6 +292,27 @@ int32_t dvn_bw6761_groth16_setup(dvn_ctx* ctx, const dvn_r1cs* cs, uint64_t seed
 int32_t dvn_bw6761_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
                                  const uint64_t r_mont[6], const uint64_t s_mont[6], uint64_t proof_out[72]);
 
+/* ---- Blob KZG on BLS12-381 (EIP-4844 / EIP-7594) ------------------------------------------------
+ * The step before every state-transition proof, /root/reference/crypto/blobs/blob.go:40-90 (BlobEvalData.Set):
+ *   dvn_kzg_blob_to_commitment   replaces Blob.ComputeCommitment   /root/reference/types/blobs.go:88-95
+ *   dvn_kzg_compute_proof        replaces Blob.ComputeProof        /root/reference/types/blobs.go:120-133  (proof, claim y)
+ *   dvn_kzg_compute_cell_proofs  replaces Blob.ComputeCellProofs   /root/reference/types/blobs.go:97-104   (128 proofs)
+ *   dvn_kzg_evaluate_barycentric mirrors EvaluateBarycentricNative /root/reference/crypto/blobs/barycentric.go:24-170
+ * Byte formats are the reference's: blob = 4096 x 32-byte big-endian field elements (types.Blob), z / y = 32 bytes big
+ * endian, commitments and proofs = 48-byte compressed G1 (types.KZGCommitment / KZGProof).  Errors as geth's kzg4844:
+ * a non-canonical blob element or evaluation point -> DVN_ERR_INVALID_ARG.
+ * dvn_kzg_setup_load takes the two G1 bases of /root/reference/config/kzg_trusted_setup.txt (config/kzg_setup.go:7-8) as
+ * 4096 x 48 compressed bytes each, in the file's (natural) order; g1_monomial may be NULL (then no cell proofs).  The setup
+ * is decompressed on the device and stays resident in HBM; it is bound to `ctx`. */
+typedef struct dvn_kzg_setup dvn_kzg_setup;
+int32_t dvn_kzg_setup_load(dvn_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t* g1_monomial, dvn_kzg_setup** out);
+int32_t dvn_kzg_setup_free(dvn_ctx* ctx, dvn_kzg_setup* setup);
+int32_t dvn_kzg_blob_to_commitment(dvn_ctx* ctx, const dvn_kzg_setup* setup, const uint8_t* blob /* 131072 */, uint8_t out[48]);
+int32_t dvn_kzg_compute_proof(dvn_ctx* ctx, const dvn_kzg_setup* setup, const uint8_t* blob, const uint8_t z[32],
+                              uint8_t proof[48], uint8_t y[32]);
+int32_t dvn_kzg_compute_cell_proofs(dvn_ctx* ctx, const dvn_kzg_setup* setup, const uint8_t* blob, uint8_t* proofs /* 128 x 48 */);
+int32_t dvn_kzg_evaluate_barycentric(dvn_ctx* ctx, const dvn_kzg_setup* setup, const uint8_t* blob, const uint8_t z[32], uint8_t y[32]);
+
 /* ---- timing of the last call's kernels, measured with HIP events on the library's own stream ---------- */
 /* which: 0 = whole device section of the last MSM/NTT call, 1 = its dominant kernel (MSM: bucket
  * accumulation; NTT: sum of butterfly passes). */

@@ -127,3 +127,97 @@ def test_blob_rejects_non_canonical(K):
         K.blob_to_field_elements(bytes(bad))
     with pytest.raises(ValueError):
         K.blob_to_field_elements(bytes(100))
+
+
+# ---------------------------------------------------------------- part 2: the HIP path (-m gpu)
+@pytest.fixture(scope="module")
+def dev(ctx, pkg):
+    s = pkg.KzgSetup.from_file(ctx, os.path.join(GOLDEN, "kzg_trusted_setup.txt"))
+    yield s
+    s.close()
+
+
+@pytest.mark.gpu
+def test_gpu_setup_decompression_matches_reference_bases(dev, ts, K, ctx, pkg):
+    """sum_i L_i = [1] and sum_i w_i L_bitrev(i) = [tau] = monomial[1] through the device MSM over the device-decompressed
+    setup: pins decompression, the bit-reversed placement and the BLS12-381 MSM against the reference's own file."""
+    ones = bytes(31) + b"\x01"
+    assert dev.compute_commitment(ones * 4096) == K.g1_compress(K.G1_GEN)
+    blob = b"".join(w.to_bytes(32, "big") for w in K.domain_brp(4096))
+    assert dev.compute_commitment(blob) == ts.g1_monomial_bytes[1]
+    # f = X^5 in evaluation form -> [tau^5]
+    blob5 = b"".join(pow(w, 5, K.R).to_bytes(32, "big") for w in K.domain_brp(4096))
+    assert dev.compute_commitment(blob5) == ts.g1_monomial_bytes[5]
+
+
+@pytest.mark.gpu
+def test_gpu_commitment(dev, ts, K, blobs):
+    for blob in (blobs[0], blobs[1], small_blob(K, 7), small_blob(K, 1, 20)):
+        assert dev.compute_commitment(blob) == K.blob_to_commitment(ts, blob)
+    assert dev.compute_commitment(bytes(131072)) == bytes([0xC0]) + bytes(47)
+
+
+@pytest.mark.gpu
+def test_gpu_proof_and_claim(dev, ts, K, blobs):
+    omega = K.domain_brp(4096)
+    cases = [(blobs[0], 12345 * 7), (blobs[1], K.R - 1), (small_blob(K, 3), 3 * 12345), (blobs[1], omega[5]), (small_blob(K, 9), omega[4095]),
+             (blobs[0], 0), (blobs[0], 1)]                                   # z = 1 = w_0 is in the domain
+    for blob, z in cases:
+        proof, y = dev.compute_proof(blob, z)
+        want_proof, want_y = K.compute_proof(ts, blob, z)
+        assert y == want_y and proof == want_proof, "z = %x" % z
+        assert dev.evaluate_barycentric(blob, z) == K.evaluate_barycentric(blob, z) == y   # barycentric.go:24-170
+
+
+@pytest.mark.gpu
+def test_gpu_cell_proofs(dev, ts, K, blobs):
+    blob = blobs[0]
+    got = dev.compute_cell_proofs(blob)
+    assert len(got) == 128 and len(set(got)) == 128
+    coeffs = K.blob_coefficients(blob)
+    for k in (0, 1, 64, 127):                                                # individual cells against the oracle
+        assert got[k] == K.compute_cell_proof(ts, blob, k, coeffs), "cell %d" % k
+    # all 128 at once: sum_k r_k proof_k == commitment to sum_k r_k q_k over the monomial basis
+    rng = random.Random(11)
+    rk = [rng.randrange(1 << 64) for _ in range(128)]
+    comb = [0] * (4096 - 64)
+    for k in range(128):
+        q = K.cell_quotient_coefficients(coeffs, k)
+        for j, v in enumerate(q):
+            comb[j] = (comb[j] + rk[k] * v) % K.R
+    want = K.g1_msm(ts.g1_monomial[:4096 - 64], comb)
+    assert K.g1_msm([K.g1_decompress(p) for p in got], rk) == want
+    # a sparse blob (most coefficients of every quotient equal): zero blob -> all proofs at infinity
+    assert dev.compute_cell_proofs(bytes(131072)) == [bytes([0xC0]) + bytes(47)] * 128
+    small = small_blob(K, 5)
+    got2 = dev.compute_cell_proofs(small)
+    c2 = K.blob_coefficients(small)
+    assert got2[77] == K.compute_cell_proof(ts, small, 77, c2)
+
+
+@pytest.mark.gpu
+def test_gpu_kzg_errors(dev, ctx, pkg, K):
+    bad = bytearray(131072); bad[32:64] = K.R.to_bytes(32, "big")
+    with pytest.raises(pkg.DvnError):
+        dev.compute_commitment(bytes(bad))
+    with pytest.raises(pkg.DvnError):
+        dev.compute_proof(bytes(131072), K.R)                                # non-canonical evaluation point
+    with pytest.raises(ValueError):
+        dev.compute_proof(bytes(131072), 1 << 256)                           # types/blobs_test.go:10 TestComputeProofRejectsOversizedPoint
+    with pytest.raises(ValueError):
+        dev.compute_commitment(bytes(100))
+    lag = bytearray(4096 * 48)
+    with pytest.raises(pkg.DvnError):
+        pkg.KzgSetup(ctx, bytes(lag))                                        # not a compressed encoding
+    lag2 = open(os.path.join(GOLDEN, "kzg_trusted_setup.txt")).read().split()
+    pts = bytearray(bytes.fromhex("".join(lag2[2:2 + 4096])))
+    pts[48 * 9 + 47] ^= 1                                                    # x no longer on the curve (or another point: the sums change)
+    try:
+        s = pkg.KzgSetup(ctx, bytes(pts))
+        s.close()
+    except pkg.DvnError as e:
+        assert "curve" in str(e)
+    no_mono = pkg.KzgSetup(ctx, bytes.fromhex("".join(lag2[2:2 + 4096])))
+    with pytest.raises(pkg.DvnError):
+        no_mono.compute_cell_proofs(bytes(131072))
+    no_mono.close()
