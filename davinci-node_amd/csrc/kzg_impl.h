@@ -151,76 +151,78 @@ __device__ __forceinline__ Fr block_sum_fr(Fr v, u32* sh) {
     return r;
 }
 
-// ---- compute_kzg_proof_impl's field part (EIP-4844), one block of 1024 threads x 4 elements:
-//   y = f(z) by the barycentric formula of crypto/blobs/barycentric.go:24-170 (or f_m when z = w_m, :99-107),
-//   q_i = (f_i - y) / (w_i - z), and compute_quotient_eval_within_domain for i = m.
-// z_int: canonical little-endian words.  consts: w_4096 (internal).  out_y: canonical integer words of y.
-static __global__ __launch_bounds__(1024) void k_kzg_quotient(const u32* __restrict__ f_ext, const u32* __restrict__ z_int, const u32* __restrict__ consts,
-                                                              u32* __restrict__ q_ext, u32* __restrict__ out_y) {
-    __shared__ u32 sh[S::NL * 1024];
-    __shared__ int s_m;
-    const u32 t = threadIdx.x;
-    if (t == 0) s_m = -1;
-    u32 zw[SW], cw[SW];
+// ---- compute_kzg_proof_impl's field part (EIP-4844) in two launches:
+//   k_kzg_terms    one thread per element, spread over the chip: w_i = w^bitrev(i), inv_i = 1/(z - w_i) (own Fermat
+//                  inversion: no batch trick needed with 4096 lanes), g_i = f_i w_i inv_i; flags m when z = w_m
+//   k_kzg_quotient one block: y = f(z) by the barycentric formula of crypto/blobs/barycentric.go:24-170 (or f_m when
+//                  z = w_m, :99-107), q_i = (f_i - y)/(w_i - z), and compute_quotient_eval_within_domain for i = m.
+// z_int: canonical little-endian words.  consts: w_4096, w_128, 1/4096 (internal).  out_y: canonical integer words of y.
+static __global__ void k_kzg_terms(const u32* __restrict__ f_ext, const u32* __restrict__ z_int, const u32* __restrict__ consts,
+                                   u32* __restrict__ inv_out, u32* __restrict__ g_out, int* __restrict__ m_out) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    u32 zw[SW], cw[SW], w[SW];
 #pragma unroll
     for (int k = 0; k < SW; ++k) { zw[k] = z_int[k]; cw[k] = consts[k]; }
     const Fr z = fe_from_canonical<S>(fe_unpack<S>(zw));
-    const Fr w1 = fe_unpack<S>(cw);                                   // stored internal (fr_store_internal)
-    __syncthreads();
-    Fr f[4], om[4], d[4];
-    bool hit[4];
+    const Fr om = pow_bits<S>(fe_unpack<S>(cw), bitrev(i, LOGN), LOGN);
+    load_words16(f_ext + (size_t)i * SW, w, SW);
+    const Fr f = fe_from_ext_mont<S>(w);
+    const Fr d = fe_sub<S>(z, om);
+    const bool hit = fe_is_zero<S>(d);
+    if (hit) *m_out = (int)i;
+    const Fr inv = fe_inv<S>(d);                                      // 0 -> 0
+    const Fr wi = fe_mul<S>(om, inv);                                 // w_i / (z - w_i)
+    u32 o[SW];
+    fe_pack<S>(fe_canonical<S>(inv), o); store_words16(inv_out + (size_t)i * SW, o, SW);
+    fe_pack<S>(fe_canonical<S>(wi), o); store_words16(g_out + (size_t)i * SW, o, SW);
+}
+static __global__ __launch_bounds__(1024) void k_kzg_quotient(const u32* __restrict__ f_ext, const u32* __restrict__ z_int, const u32* __restrict__ consts,
+                                                              const u32* __restrict__ inv_in, const u32* __restrict__ g_in, const int* __restrict__ m_in,
+                                                              u32* __restrict__ q_ext, u32* __restrict__ out_y) {
+    __shared__ u32 sh[S::NL * 1024];
+    const u32 t = threadIdx.x;
+    const int m = *m_in;
+    u32 zw[SW], nw[SW];
+#pragma unroll
+    for (int k = 0; k < SW; ++k) { zw[k] = z_int[k]; nw[k] = consts[2 * SW + k]; }
+    const Fr z = fe_from_canonical<S>(fe_unpack<S>(zw));
+    Fr f[4], inv[4], wi[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const u32 i = t + 1024 * e;
         u32 w[SW];
-        load_words16(f_ext + (size_t)i * SW, w, SW);
-        f[e] = fe_from_ext_mont<S>(w);
-        om[e] = pow_bits<S>(w1, bitrev(i, LOGN), LOGN);
-        d[e] = fe_sub<S>(z, om[e]);
-        hit[e] = fe_is_zero<S>(d[e]);
-        if (hit[e]) { s_m = (int)i; d[e] = fe_one<S>(); }
+        load_words16(f_ext + (size_t)i * SW, w, SW); f[e] = fe_from_ext_mont<S>(w);
+        load_words16(inv_in + (size_t)i * SW, w, SW); inv[e] = fe_unpack<S>(w);
+        load_words16(g_in + (size_t)i * SW, w, SW); wi[e] = fe_unpack<S>(w);
     }
-    // 1 / (z - w_i): four per thread with one inversion
-    Fr inv[4];
-    {
-        const Fr p1 = fe_mul<S>(d[0], d[1]), p2 = fe_mul<S>(p1, d[2]), p3 = fe_mul<S>(p2, d[3]);
-        Fr a = fe_inv<S>(p3);
-        inv[3] = fe_mul<S>(a, p2); a = fe_mul<S>(a, d[3]);
-        inv[2] = fe_mul<S>(a, p1); a = fe_mul<S>(a, d[2]);
-        inv[1] = fe_mul<S>(a, d[0]); inv[0] = fe_mul<S>(a, d[1]);
-    }
-    __syncthreads();
-    const int m = s_m;
     Fr y;
     if (m < 0) {
         Fr acc = fe_zero<S>();
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = fe_add<S>(acc, fe_mul<S>(fe_mul<S>(f[e], om[e]), inv[e]));
+        for (int e = 0; e < 4; ++e) acc = fe_add<S>(acc, fe_mul<S>(f[e], wi[e]));
         const Fr sum = block_sum_fr(acc, sh);
-        // (z^4096 - 1) / 4096
-        Fr zp = z;
+        Fr zp = z;                                                    // (z^4096 - 1) / 4096
         for (u32 k = 0; k < LOGN; ++k) zp = fe_sqr<S>(zp);
-        u32 nw[SW] = {N, 0, 0, 0, 0, 0, 0, 0};
-        const Fr ninv = fe_inv<S>(fe_from_canonical<S>(fe_unpack<S>(nw)));
-        y = fe_mul<S>(sum, fe_mul<S>(fe_sub<S>(zp, fe_one<S>()), ninv));
+        y = fe_mul<S>(sum, fe_mul<S>(fe_sub<S>(zp, fe_one<S>()), fe_unpack<S>(nw)));
     } else {
         Fr mine = fe_zero<S>();
 #pragma unroll
-        for (int e = 0; e < 4; ++e) if (hit[e]) mine = f[e];
+        for (int e = 0; e < 4; ++e) if ((int)(t + 1024 * e) == m) mine = f[e];
         y = block_sum_fr(mine, sh);                                   // exactly one non-zero term: f_m
     }
     Fr q[4], acc2 = fe_zero<S>();
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const Fr g = fe_mul<S>(fe_sub<S>(f[e], y), inv[e]);           // (f_i - y) / (z - w_i)
-        q[e] = fe_neg<S>(g);
-        if (!hit[e]) acc2 = fe_add<S>(acc2, fe_mul<S>(g, om[e]));
+        const Fr df = fe_sub<S>(f[e], y);
+        q[e] = fe_neg<S>(fe_mul<S>(df, inv[e]));                      // (f_i - y) / (w_i - z); inv_m = 0
+        acc2 = fe_add<S>(acc2, fe_mul<S>(df, wi[e]));                 // (f_i - y) w_i / (z - w_i); the i = m term is 0
     }
     if (m >= 0) {                                                     // q_m = sum_{i != m} (f_i - y) w_i / (z (z - w_i))
         const Fr u = block_sum_fr(acc2, sh);
         const Fr qm = fe_mul<S>(u, fe_inv<S>(z));
 #pragma unroll
-        for (int e = 0; e < 4; ++e) if (hit[e]) q[e] = qm;
+        for (int e = 0; e < 4; ++e) if ((int)(t + 1024 * e) == m) q[e] = qm;
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -279,7 +281,11 @@ struct dvn_kzg_setup {
     dvn_points* monomial = nullptr;          // [tau^j]G1 (cell proofs), may be NULL
     dvn_domain* dom = nullptr;               // BLS12-381 Fr domain of 4096
     uint8_t* d_bytes = nullptr;              // staging: blob (128 KiB) / compressed points in (192 KiB) / out (6 KiB)
-    u32 *d_f = nullptr, *d_q = nullptr, *d_cellq = nullptr, *d_res = nullptr, *d_small = nullptr;   // d_small: z, y, consts, err
+    u32 *d_f = nullptr, *d_q = nullptr, *d_cellq = nullptr, *d_res = nullptr, *d_small = nullptr;   // d_small: z, y, consts, err, m
+    u32 *d_inv = nullptr, *d_g = nullptr;                                                          // 1/(z - w_i), w_i/(z - w_i)
+    // expanded tables (row w = 2^(c w) * P): all windows of a scalar vector share one bucket set, no window combine
+    u32 *tab_lagrange = nullptr, *tab_monomial = nullptr;
+    u32 c_single = 0, rows_single = 0, c_cells = 0, rows_cells = 0;
 };
 
 static int32_t kzg_points_from_compressed(dvn_ctx* ctx, dvn_kzg_setup* s, const uint8_t* bytes48, u32 brp_bits, dvn_points** out) {
@@ -316,7 +322,7 @@ static void kzg_setup_destroy(dvn_kzg_setup* s) {            // no locking, no c
         for (u32* q : ptrs) if (q) (void)hipFree(q);
         delete d;
     }
-    void* bufs[] = {s->d_bytes, s->d_f, s->d_q, s->d_cellq, s->d_res, s->d_small};
+    void* bufs[] = {s->d_bytes, s->d_f, s->d_q, s->d_cellq, s->d_res, s->d_small, s->d_inv, s->d_g, s->tab_lagrange, s->tab_monomial};
     for (void* b : bufs) if (b) (void)hipFree(b);
     delete s;
 }
@@ -340,16 +346,22 @@ extern "C" int32_t dvn_kzg_setup_load(dvn_ctx* ctx, const uint8_t* g1_lagrange, 
     auto alloc = [&](void** p, size_t bytes) -> int32_t { HIP_TRY(hipMalloc(p, bytes)); return DVN_OK; };
     if ((rc = alloc((void**)&s->d_bytes, (size_t)kzg::N * 48)) || (rc = alloc((void**)&s->d_f, (size_t)kzg::N * kzg::SW * 4)) ||
         (rc = alloc((void**)&s->d_q, (size_t)kzg::N * kzg::SW * 4)) || (rc = alloc((void**)&s->d_res, (size_t)kzg::CELLS * G1_381::XW * 4)) ||
-        (rc = alloc((void**)&s->d_small, 512)) ||
+        (rc = alloc((void**)&s->d_small, 512)) || (rc = alloc((void**)&s->d_inv, (size_t)kzg::N * kzg::SW * 4)) || (rc = alloc((void**)&s->d_g, (size_t)kzg::N * kzg::SW * 4)) ||
         (g1_monomial && (rc = alloc((void**)&s->d_cellq, (size_t)kzg::CELLS * kzg::QN * kzg::SW * 4)))) { kzg_setup_destroy(s); return rc; }
-    // constants: w_4096 and w_128 in internal form at d_small + 16 / + 24 (u32 words)
-    u32 h[2 * kzg::SW];
+    // constants: w_4096, w_128, 1/4096 in internal form at d_small + 16 / + 24 / + 32 (u32 words); err at + 64, m at + 65
+    u32 h[3 * kzg::SW];
     fr_store_internal<Fr381Cfg>(fr_root_of_unity<Fr381Cfg>(12), h);
     fr_store_internal<Fr381Cfg>(fr_root_of_unity<Fr381Cfg>(7), h + kzg::SW);
+    fr_store_internal<Fr381Cfg>(fe_inv<Fr381Cfg>(fr_from_u64<Fr381Cfg>(kzg::N)), h + 2 * kzg::SW);
     hipError_t e = hipMemcpy(s->d_small + 16, h, sizeof(h), hipMemcpyHostToDevice);
     if (e != hipSuccess) { kzg_setup_destroy(s); (void)hipGetLastError(); return fail(DVN_ERR_DEVICE, "constant upload failed: %s", hipGetErrorString(e)); }
     if ((rc = kzg_points_from_compressed(ctx, s, g1_lagrange, kzg::LOGN, &s->lagrange_brp)) ||
         (g1_monomial && (rc = kzg_points_from_compressed(ctx, s, g1_monomial, 0, &s->monomial)))) { kzg_setup_destroy(s); return rc; }
+    // expanded tables, once per setup: window sizes from the sweep in tools/gpu_kzg_perf.py (DVN_KZG_C / DVN_KZG_CELL_C override)
+    auto env_c = [](const char* name, u32 dflt) { const char* v = getenv(name); const int x = v ? atoi(v) : 0; return (u32)((x >= 4 && x <= 16) ? x : dflt); };
+    s->c_single = env_c("DVN_KZG_C", 13); s->c_cells = env_c("DVN_KZG_CELL_C", 11);
+    if ((rc = msm_row_table_create<G1_381>(ctx, s->lagrange_brp, kzg::N, s->c_single, &s->rows_single, &s->tab_lagrange)) ||
+        (g1_monomial && (rc = msm_row_table_create<G1_381>(ctx, s->monomial, kzg::QN, s->c_cells, &s->rows_cells, &s->tab_monomial)))) { kzg_setup_destroy(s); return rc; }
     *out = s;
     return DVN_OK;
 }
@@ -367,14 +379,11 @@ static int32_t kzg_load_blob(dvn_ctx* ctx, const dvn_kzg_setup* s, const uint8_t
     if (herr) return fail(DVN_ERR_INVALID_ARG, "blob element is not a canonical field element");
     return DVN_OK;
 }
-// `batch` MSMs of n scalars each over pts[0, n) -> `batch` compressed points in out48 (caller holds ctx->mu)
-static int32_t kzg_commit(dvn_ctx* ctx, const dvn_kzg_setup* s, const dvn_points* pts, size_t n, const u32* d_scalars, u32 batch, uint8_t* out48) {
-    static const u32 c_single = []() { const char* v = getenv("DVN_KZG_C"); const int x = v ? atoi(v) : 0; return (u32)((x >= 4 && x <= 16) ? x : 0); }();
-    static const u32 c_cells = []() { const char* v = getenv("DVN_KZG_CELL_C"); const int x = v ? atoi(v) : 0; return (u32)((x >= 4 && x <= 16) ? x : 9); }();
-    u32 c = c_cells, nwin;
-    if (batch == 1) { msm_plan(n, &c, &nwin, Fr381Cfg::BITS); if (c_single) c = c_single; }
+// `batch` MSMs of n scalars each over pts[0, n) (expanded table `tab`, window c) -> `batch` compressed points in out48
+// (caller holds ctx->mu)
+static int32_t kzg_commit(dvn_ctx* ctx, const dvn_kzg_setup* s, const dvn_points* pts, const u32* tab, u32 c, size_t n, const u32* d_scalars, u32 batch, uint8_t* out48) {
     MsmLane* L = nullptr;
-    TRY(msm_batched_submit<G1_381>(ctx, pts, 0, n, d_scalars, batch, c, s->d_res, &L));
+    TRY(msm_batched_submit<G1_381>(ctx, pts, 0, n, d_scalars, batch, c, s->d_res, &L, tab));
     uint8_t* d_out = s->d_bytes + (size_t)kzg::N * 40;                 // tail of the staging buffer (6 KiB needed)
     kzg::k_g1_compress<<<(batch + 63) / 64, 64, 0, L->stream>>>(s->d_res, batch, d_out);
     hipError_t e = hipGetLastError();
@@ -389,7 +398,7 @@ extern "C" int32_t dvn_kzg_blob_to_commitment(dvn_ctx* ctx, const dvn_kzg_setup*
     if (!s || !blob || !out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     std::lock_guard<std::mutex> lk(ctx->mu);
     TRY(kzg_load_blob(ctx, s, blob));
-    return kzg_commit(ctx, s, s->lagrange_brp, kzg::N, s->d_f, 1, out);
+    return kzg_commit(ctx, s, s->lagrange_brp, s->tab_lagrange, s->c_single, kzg::N, s->d_f, 1, out);
 }
 
 static int32_t kzg_scalar_from_be(const uint8_t z_be[32], u32 zw[8]) {
@@ -402,7 +411,10 @@ static int32_t kzg_scalar_from_be(const uint8_t z_be[32], u32 zw[8]) {
 static int32_t kzg_quotient(dvn_ctx* ctx, const dvn_kzg_setup* s, const u32 zw[8], uint8_t y_out[32]) {
     u32 yw[8];
     HIP_TRY(hipMemcpyAsync(s->d_small, zw, 32, hipMemcpyHostToDevice, ctx->stream));
-    kzg::k_kzg_quotient<<<1, 1024, 0, ctx->stream>>>(s->d_f, s->d_small, s->d_small + 16, s->d_q, s->d_small + 8);
+    int* d_m = (int*)(s->d_small + 65);
+    HIP_TRY(hipMemsetAsync(d_m, 0xff, 4, ctx->stream));                 // m = -1: z outside the domain
+    kzg::k_kzg_terms<<<kzg::N / 64, 64, 0, ctx->stream>>>(s->d_f, s->d_small, s->d_small + 16, s->d_inv, s->d_g, d_m);
+    kzg::k_kzg_quotient<<<1, 1024, 0, ctx->stream>>>(s->d_f, s->d_small, s->d_small + 16, s->d_inv, s->d_g, d_m, s->d_q, s->d_small + 8);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(yw, s->d_small + 8, 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -428,7 +440,7 @@ extern "C" int32_t dvn_kzg_compute_proof(dvn_ctx* ctx, const dvn_kzg_setup* s, c
     std::lock_guard<std::mutex> lk(ctx->mu);
     TRY(kzg_load_blob(ctx, s, blob));
     TRY(kzg_quotient(ctx, s, zw, y));
-    return kzg_commit(ctx, s, s->lagrange_brp, kzg::N, s->d_q, 1, proof);
+    return kzg_commit(ctx, s, s->lagrange_brp, s->tab_lagrange, s->c_single, kzg::N, s->d_q, 1, proof);
 }
 
 extern "C" int32_t dvn_kzg_compute_cell_proofs(dvn_ctx* ctx, const dvn_kzg_setup* s, const uint8_t* blob, uint8_t* proofs /* 128 x 48 */) {
@@ -441,5 +453,5 @@ extern "C" int32_t dvn_kzg_compute_cell_proofs(dvn_ctx* ctx, const dvn_kzg_setup
     TRY(ntt_device<Fr381Cfg>(ctx, s->dom, s->d_f, 1, DVN_DIT, 0));
     kzg::k_cell_quotients<<<kzg::CELLS * kzg::CELL / 64, 64, 0, ctx->stream>>>(s->d_f, s->d_small + 16, s->d_cellq);
     HIP_TRY(hipGetLastError());
-    return kzg_commit(ctx, s, s->monomial, kzg::QN, s->d_cellq, kzg::CELLS, proofs);
+    return kzg_commit(ctx, s, s->monomial, s->tab_monomial, s->c_cells, kzg::QN, s->d_cellq, kzg::CELLS, proofs);
 }

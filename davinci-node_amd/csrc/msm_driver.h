@@ -190,16 +190,23 @@ static inline size_t s2_lds() { return ((size_t)4 * 1024 + 80 + ST) * 4 + (size_
 // the accumulate / fix kernels see ONE window of W * nb buckets, the reduction runs per real window afterwards.
 template <class Cv>
 static int32_t msm_windows_staged(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
-                                  u32 c, u32 win_lo, u32 win_hi, u32 batch = 1, u32* d_batch_out = nullptr) {
+                                  u32 c, u32 win_lo, u32 win_hi, u32 batch = 1, u32* d_batch_out = nullptr, const u32* row_table = nullptr) {
     // d_batch_out != NULL: `scalars` holds batch x n device scalars (vector b at [b * n, (b + 1) * n)) over the SAME n points; every
     // (vector, window) pair is a virtual window of the one sorted entry list, the window sums are combined per vector on
     // the device (k_batch_horner) and the batch internal xyzz results stay in d_batch_out (device).
     typedef typename PairedOf<Cv>::type KC;
     constexpr u32 LPP = Lanes<KC>::LPP;
     static_assert(KC::XW == Cv::XW && KC::AW == Cv::AW, "paired and ordinary images must agree");
-    const u32 W = (win_hi - win_lo) * batch;
+    // row_table != NULL (batched only): the points are an expanded table, row w = 2^(c w) * P_i (n points per row, win_hi
+    // rows).  The digit array has the same memory layout, but is read as ONE virtual window per vector with win_hi * n
+    // entries whose point reference is the table position w * n + i: all windows of a vector share one bucket set, there
+    // is one bucket reduction per vector and no window combine (DESIGN.md §4b carried over to the batched path).
     const bool batched = d_batch_out != nullptr;
-    if ((batch != 1 && !batched) || (batched && (win_lo != 0 || batch == 0 || !(flags & DVN_MSM_SCALARS_ON_DEVICE)))) return fail(DVN_ERR_INVALID_ARG, "batched MSM: all windows, device scalars, device output");
+    const bool rowed = row_table != nullptr;
+    if ((batch != 1 && !batched) || (rowed && !batched) || (batched && (win_lo != 0 || batch == 0 || !(flags & DVN_MSM_SCALARS_ON_DEVICE)))) return fail(DVN_ERR_INVALID_ARG, "batched MSM: all windows, device scalars, device output");
+    const size_t n_src = n;                                            // scalars per vector
+    if (rowed) n = n_src * win_hi;                                     // entries per virtual window
+    const u32 W = rowed ? batch : (win_hi - win_lo) * batch;
     const u32 nb = 1u << (c - 1);
     const u32 lob = c - 1 < 7 ? c - 1 : 7, lb = nb >> lob;             // <= 256 bins per window, 2^lob sub-buckets per bin
     const size_t total = (size_t)W * n;
@@ -265,7 +272,7 @@ static int32_t msm_windows_staged(dvn_ctx* ctx, MsmLane& L, const dvn_points* pt
     TRY(sort_attrs<int16_t>());
     HIP_TRY(hipEventRecord(L.ev[0], st));
     HIP_TRY(hipMemsetAsync(totals, 0, 16, st));
-    if (batched) k_digits16_batched<typename ScalarOf<Cv>::S><<<(unsigned)((n * batch + 255) / 256), 256, 0, st>>>(d_scalars, n, batch, c, win_hi, digits);
+    if (batched) k_digits16_batched<typename ScalarOf<Cv>::S><<<(unsigned)((n_src * batch + 255) / 256), 256, 0, st>>>(d_scalars, n_src, batch, c, win_hi, digits);
     else k_digits16<typename ScalarOf<Cv>::S><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_scalars, n, c, win_lo, win_hi, digits);
     DBG_SYNC("k_digits16");
     k_s1_hist<int16_t><<<W * tpw, 1024, (size_t)lb * 4, st>>>(digits, n, tpw, lob, lb, hist1);
@@ -284,7 +291,7 @@ static int32_t msm_windows_staged(dvn_ctx* ctx, MsmLane& L, const dvn_points* pt
     k_s2_scatter<<<max_pieces, 1024, s2_lds(), st>>>(bin_base, piece_base, hbins, p1_ref, p1_lo, lob, counts, cursor, sorted, offsets);
     DBG_SYNC("k_s2_scatter");
     HIP_TRY(hipEventRecord(L.ev[2], st));
-    k_accumulate<KC><<<(unsigned)(((size_t)nseg * LPP + 127) / 128), 128, acc_lds_probe(), st>>>(pts->d, off, sorted, offsets, counts, totals, buckets,
+    k_accumulate<KC><<<(unsigned)(((size_t)nseg * LPP + 127) / 128), 128, acc_lds_probe(), st>>>(rowed ? row_table : pts->d, rowed ? 0 : off, sorted, offsets, counts, totals, buckets,
                                                                           edge_first, edge_last, total, vb, seg, nseg, 1);
     DBG_SYNC("k_accumulate");
     HIP_TRY(hipEventRecord(L.ev[3], st));
@@ -304,6 +311,11 @@ static int32_t msm_windows_staged(dvn_ctx* ctx, MsmLane& L, const dvn_points* pt
     DBG_SYNC("k_bucket_reduce");
     k_window_finalize<KC><<<W, 64 * LPP, (size_t)64 * Cv::XW * 4, st>>>(partials, wsums, W, bpw);
     DBG_SYNC("k_window_finalize");
+    if (rowed) {
+        HIP_TRY(hipMemcpyAsync(d_batch_out, wsums, (size_t)W * Cv::XW * 4, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipEventRecord(L.ev[1], st));
+        return DVN_OK;
+    }
     if (batched) {
         k_batch_horner<Cv><<<(batch + 63) / 64, 64, 0, st>>>(wsums, win_hi, c, batch, d_batch_out);
         DBG_SYNC("k_batch_horner");
@@ -591,19 +603,34 @@ static int32_t msm_rows_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, 
 // (device).  ENQUEUE only, on a free lane; lane_wait() completes it.  Used by the blob KZG cell proofs (dvn_kzg.hip): 128
 // quotient polynomials committed over one monomial basis.
 template <class Cv>
-static int32_t msm_batched_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, u32 batch, u32 c, u32* d_out, MsmLane** lane_out) {
+static int32_t msm_batched_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, u32 batch, u32 c, u32* d_out, MsmLane** lane_out,
+                                  const u32* row_table = nullptr) {
     if (off > pts->n || n > pts->n - off) return fail(DVN_ERR_INVALID_ARG, "len(points) != len(scalars): range [%zu, %zu) outside point set of %zu", off, off + n, pts->n);
     if (n == 0 || batch == 0 || c < 2 || c > 16) return fail(DVN_ERR_INVALID_ARG, "batched MSM: empty input or window size outside [2, 16]");
     MsmLane* L = nullptr;
     TRY(lane_acquire(ctx, &L));
     const u32 nwin = ScalarOf<Cv>::S::BITS / c + 1;
     L->curve = pts->curve; L->W = 0; L->expanded = false; L->c = c; L->nwin = nwin;
-    int32_t rc = msm_windows_staged<Cv>(ctx, *L, pts, off, n, (const uint64_t*)d_scalars, DVN_MSM_SCALARS_ON_DEVICE, c, 0, nwin, batch, d_out);
+    int32_t rc = msm_windows_staged<Cv>(ctx, *L, pts, off, n, (const uint64_t*)d_scalars, DVN_MSM_SCALARS_ON_DEVICE, c, 0, nwin, batch, d_out, row_table);
     if (rc != DVN_OK) { (void)hipStreamSynchronize(L->stream); L->busy = false; return rc; }
     *lane_out = L;
     return DVN_OK;
 }
 
+// expanded table for the batched path: `rows` rows of the first n points of pts (row w = 2^(c w) * P_i); caller frees it
+template <class Cv>
+static int32_t msm_row_table_create(dvn_ctx* ctx, const dvn_points* pts, size_t n, u32 c, u32* rows_out, u32** table_out) {
+    if (n == 0 || n > pts->n) return fail(DVN_ERR_INVALID_ARG, "row table: bad point count");
+    const u32 rows = ScalarOf<Cv>::S::BITS / c + 1;
+    u32* t = nullptr;
+    HIP_TRY(hipMalloc((void**)&t, (size_t)rows * n * Cv::AW * 4));
+    hipError_t e = hipMemcpyAsync(t, pts->d, n * Cv::AW * 4, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) { k_points_expand<Cv><<<(unsigned)((n + 63) / 64), 64, 0, ctx->stream>>>(t, n, c, rows); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(t); (void)hipGetLastError(); return fail(DVN_ERR_DEVICE, "row table: %s", hipGetErrorString(e)); }
+    *rows_out = rows; *table_out = t;
+    return DVN_OK;
+}
 // complete it: host-side window combine (host_fast.h)
 template <class Cv>
 static int32_t msm_collect(dvn_ctx* ctx, MsmLane& L, typename FastHost<Cv>::G::X* out) {
