@@ -264,6 +264,28 @@ def main():
                            "key_sizes": key.sizes, "witness": "resident in HBM; solve = sparse (A w, B w, C w) on device"}
             ctx.free(dw); key.free(); cs.free()
 
+        # row f3: what BlobEvalData.Set costs before every state-transition proof (crypto/blobs/blob.go:40-90): blob commitment,
+        # 128 cell proofs and the opening proof at z, over the trusted setup the reference embeds (tests/golden copy)
+        golden = os.path.join(ROOT, "tests", "golden")
+        if os.path.exists(os.path.join(golden, "kzg_trusted_setup.txt")):
+            ks = pkg.KzgSetup.from_file(ctx, os.path.join(golden, "kzg_trusted_setup.txt"))
+            blob = bytes.fromhex(open(os.path.join(golden, "kzg_blobdata1.txt")).read().strip())
+            lines = open(os.path.join(golden, "kzg_trusted_setup.txt")).read().split()
+            def best(f, reps=5):
+                b = 1e9
+                for _ in range(reps):
+                    t0 = time.perf_counter(); f(); b = min(b, time.perf_counter() - t0)
+                return round(b * 1e3, 3)
+            def set_equiv():
+                ks.compute_commitment(blob); ks.compute_cell_proofs(blob); ks.compute_proof(blob, 0x1234567)
+            ones = (bytes(31) + b"\x01") * 4096       # sum of the Lagrange basis = [1]G1 = first monomial point of the file
+            extras["blob_kzg_bls12381"] = {"ms_commitment": best(lambda: ks.compute_commitment(blob)),
+                                           "ms_proof_at_z": best(lambda: ks.compute_proof(blob, 0x1234567)),
+                                           "ms_128_cell_proofs": best(lambda: ks.compute_cell_proofs(blob)),
+                                           "ms_blob_eval_data_set": best(set_equiv),
+                                           "setup_checked": ks.compute_commitment(ones).hex() == lines[2 + 4096 + 65]}
+            ks.close()
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = n * args.steps / elapsed / 1e6
