@@ -242,6 +242,31 @@ def main():
                                            "achieved_GBps": round(2 * (1 << ln) * 64 / (fi * 1e-3) / 1e9, 1),
                                            "frac_of_hbm_peak": round(2 * (1 << ln) * 64 / (fi * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                                            "round_trip_identity": bool((x0 == x1).all())}
+        # config 4 ("aggregator full PLONK proof"): the reference has no PLONK circuit -- this is an explicitly
+        # SYNTHETIC COMPOSITION of the two primitives in the shape of a PLONK prover with 2^22 gates over one KZG SRS:
+        # 9 commitment / opening MSMs of 2^22 (L, R, O, Z, H1..H3, W_z, W_zw) with three in flight, 4 iNTT of 2^22,
+        # 8 coset NTTs and 1 coset iNTT over the 4n = 2^24 quotient domain.  The reference-faithful aggregator proof is
+        # the BW6-761 Groth16 leg below.
+        if args.log_n == 22:
+            dom22 = ctx.domain(22)
+            def plonk_shape():
+                tk = []
+                for _ in range(9):
+                    tk.append(ctx.msm_g1_submit(pts, scal_dev, n=n))
+                    if len(tk) == 3:
+                        ctx.msm_g1_collect(tk.pop(0))
+                for _ in range(4):
+                    ctx.ntt(dom22, dx, True, pkg.DIF)
+                for _ in range(8):
+                    ctx.ntt(dom, dx, False, pkg.DIT, True)
+                ctx.ntt(dom, dx, True, pkg.DIF, True)
+                while tk:
+                    ctx.msm_g1_collect(tk.pop(0))
+            plonk_shape()
+            t0 = time.perf_counter(); plonk_shape(); ctx.synchronize(); dtp = time.perf_counter() - t0
+            extras["plonk_shaped_composition_2^22"] = {"ms": round(dtp * 1e3, 2), "compositions_per_s": round(1 / dtp, 2),
+                                                       "what": "SYNTHETIC: 9 G1 MSMs 2^22 over one SRS + 4 iNTT 2^22 + 8 coset NTT 2^24 + 1 coset iNTT 2^24; no PLONK circuit exists in the reference"}
+            dom22.free()
         ctx.free(dx); dom.free(); del x0, x1
         # config 5 (single GPU): statetransition-shaped synthetic Groth16, n = 2^20 constraints, 8 public inputs + constant;
         # and the same shape on the voteverifier's curve (BLS12-377, 60 such proofs per batch in the reference) and on the

@@ -118,6 +118,9 @@ def load_library():
         "dvn_bls12381_r1cs_synthetic": (i32, [u64, u32, u32, C.POINTER(vp)]),
         "dvn_bls12381_groth16_setup": (i32, [vp, vp, u64, C.POINTER(vp)]),
         "dvn_bls12381_groth16_prove": (i32, [vp, vp, vp, u32, vp, vp, vp]),
+        "dvn_r1cs_synthetic_committed": (i32, [u64, u32, u32, u32, C.POINTER(vp)]),
+        "dvn_groth16_prove_committed": (i32, [vp, vp, vp, u32, vp, vp, vp, vp, vp, vp]),
+        "dvn_keccak256": (i32, [vp, sz, vp]),
         "dvn_kzg_setup_load": (i32, [vp, vp, vp, C.POINTER(vp)]),
         "dvn_kzg_setup_free": (i32, [vp, vp]),
         "dvn_kzg_blob_to_commitment": (i32, [vp, vp, vp, vp]),
@@ -167,6 +170,7 @@ EXPORTED_SYMBOLS = [
     "dvn_bls12381_points_upload_g1", "dvn_bls12381_points_upload_g2", "dvn_bls12381_points_synthetic_g1", "dvn_bls12381_points_download",
     "dvn_bls12381_scalars_synthetic", "dvn_bls12381_msm_g1", "dvn_bls12381_msm_g2", "dvn_bls12381_ntt_domain", "dvn_bls12381_ntt", "dvn_bls12381_groth16_compute_h",
     "dvn_bls12381_r1cs_synthetic", "dvn_bls12381_groth16_setup", "dvn_bls12381_groth16_prove", "dvn_r1cs_curve",
+    "dvn_r1cs_synthetic_committed", "dvn_groth16_prove_committed", "dvn_keccak256",
     "dvn_kzg_setup_load", "dvn_kzg_setup_free", "dvn_kzg_blob_to_commitment", "dvn_kzg_compute_proof", "dvn_kzg_compute_cell_proofs",
     "dvn_kzg_evaluate_barycentric",
     "dvn_bw6761_points_upload", "dvn_bw6761_points_synthetic", "dvn_bw6761_points_download", "dvn_bw6761_scalars_synthetic", "dvn_bw6761_msm",
@@ -400,12 +404,17 @@ class Context:
 class R1CS:
     """Host-side sparse R1CS handle (dvn_r1cs): the synthetic multiplication-gate instance of SURVEY.md §8d."""
 
-    def __init__(self, seed: int, n_constraints: int, n_public: int, curve: str = "bn254"):
+    def __init__(self, seed: int, n_constraints: int, n_public: int, curve: str = "bn254", n_committed: int = 0):
         self.L = load_library()
         self.curve = curve
+        self.n_committed = n_committed
         h = C.c_void_p()
-        fn = self.L.dvn_r1cs_synthetic if curve == "bn254" else getattr(self.L, f"dvn_{curve}_r1cs_synthetic")
-        rc = fn(seed, n_constraints, n_public, C.byref(h))
+        if n_committed:
+            assert curve == "bn254", "committed instances exist on BN254 (the statetransition curve)"
+            rc = self.L.dvn_r1cs_synthetic_committed(seed, n_constraints, n_public, n_committed, C.byref(h))
+        else:
+            fn = self.L.dvn_r1cs_synthetic if curve == "bn254" else getattr(self.L, f"dvn_{curve}_r1cs_synthetic")
+            rc = fn(seed, n_constraints, n_public, C.byref(h))
         if rc != 0:
             raise DvnError(rc, self.L.dvn_last_error(None).decode())
         self.h = h
@@ -452,6 +461,18 @@ class Groth16Key:
             witness = np.ascontiguousarray(witness, dtype=np.uint64); wp, fl = _host(witness), 0
         self.ctx._chk(getattr(self.ctx.L, self._prefix + "groth16_prove")(self.ctx.h, self.h, wp, fl, _host(r_mont), _host(s_mont), _host(out)))
         return {"Ar": out[0:a1].copy(), "Bs": out[a1:a1 + a2].copy(), "Krs": out[a1 + a2:2 * a1 + a2].copy()}
+
+    def prove_committed(self, witness, r_mont: np.ndarray, s_mont: np.ndarray) -> dict:
+        """Proof with one BSB22 commitment (BN254): adds 'Commitment', 'CommitmentPok' (8 uint64 each) and 'challenge' (4)."""
+        assert self.curve == "bn254"
+        out = np.zeros(32, dtype=np.uint64); cm = np.zeros(8, dtype=np.uint64); pok = np.zeros(8, dtype=np.uint64); ch = np.zeros(4, dtype=np.uint64)
+        r_mont = np.ascontiguousarray(r_mont, dtype=np.uint64); s_mont = np.ascontiguousarray(s_mont, dtype=np.uint64)
+        if isinstance(witness, (int, np.integer)):
+            wp, fl = C.c_void_p(int(witness)), 1
+        else:
+            witness = np.ascontiguousarray(witness, dtype=np.uint64); wp, fl = _host(witness), 0
+        self.ctx._chk(self.ctx.L.dvn_groth16_prove_committed(self.ctx.h, self.h, wp, fl, _host(r_mont), _host(s_mont), _host(out), _host(cm), _host(pok), _host(ch)))
+        return {"Ar": out[0:8].copy(), "Bs": out[8:24].copy(), "Krs": out[24:32].copy(), "Commitment": cm, "CommitmentPok": pok, "challenge": ch}
 
     def prove_shard(self, witness, rank: int, world: int) -> np.ndarray:
         """This rank's partial results of the five MSMs (BN254 keys): (72,) uint64 to be all-gathered."""

@@ -65,7 +65,7 @@ extern "C" void dvn_r1cs_free(dvn_r1cs* cs) { delete cs; }
 extern "C" int32_t dvn_groth16_pk_free(dvn_ctx* ctx, dvn_groth16_pk* pk) {
     TRY(enter(ctx));
     if (!pk) return DVN_OK;
-    dvn_points* ps[] = {pk->A, pk->B, pk->K, pk->Z, pk->B2};
+    dvn_points* ps[] = {pk->A, pk->B, pk->K, pk->Z, pk->B2, pk->Basis, pk->BasisSigma};
     for (dvn_points* p : ps) if (p) (void)dvn_points_free(ctx, p);
     if (pk->dom) (void)dvn_ntt_domain_free(ctx, pk->dom);
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -81,7 +81,7 @@ extern "C" int32_t dvn_groth16_pk_free(dvn_ctx* ctx, dvn_groth16_pk* pk) {
 extern "C" int32_t dvn_groth16_pk_info(const dvn_groth16_pk* pk, uint32_t* log_n, uint64_t* sizes /* nA, nB, nK, nZ, nB2 */) {
     if (!pk) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (log_n) *log_n = pk->log_n;
-    if (sizes) { sizes[0] = pk->nA; sizes[1] = pk->nB; sizes[2] = pk->m - pk->n_public; sizes[3] = pk->n; sizes[4] = pk->nB; }
+    if (sizes) { sizes[0] = pk->nA; sizes[1] = pk->nB; sizes[2] = pk->m - pk->k_first; sizes[3] = pk->n; sizes[4] = pk->nB; }
     return DVN_OK;
 }
 
@@ -159,5 +159,125 @@ extern "C" int32_t dvn_pedersen_commit(dvn_ctx* ctx, const dvn_points* basis, co
     uint64_t j[12];
     H1::write_jac(c, j); memcpy(commitment_out, j, 64); if (H1::is_inf(c)) memset(commitment_out, 0, 64);
     H1::write_jac(k, j); memcpy(pok_out, j, 64); if (H1::is_inf(k)) memset(pok_out, 0, 64);
+    return DVN_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------
+// Groth16 with ONE BSB22 commitment -- the statetransition shape: 8 public inputs + 1 commitment wire
+// (/root/reference/config/statetransition_vkey.sol:97-114, solidity/solidity.go:57-65).  gnark's Prove (SURVEY.md row a10,
+// steps (1)-(2)) computes, inside the solver's commitment hint, Commitment = MSM(pk.CommitmentKeys[0].Basis, committed wires),
+// derives the challenge that becomes the commitment wire, finishes the solve, and adds CommitmentPok =
+// MSM(BasisExpSigma, committed wires) (one commitment: BatchProve's fold is the identity).  The challenge is what the
+// reference's Solidity verifier recomputes: keccak256(C.x || C.y || publicCommitted) mod r (statetransition_vkey.sol:659-676).
+// ------------------------------------------------------------------------------------------------------
+static void keccak_f1600(uint64_t st[25]) {
+    static const uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808AULL, 0x8000000080008000ULL, 0x000000000000808BULL, 0x0000000080000001ULL,
+                                    0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008AULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000AULL,
+                                    0x000000008000808BULL, 0x800000000000008BULL, 0x8000000000008089ULL, 0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL,
+                                    0x000000000000800AULL, 0x800000008000000AULL, 0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    static const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};   // [x + 5y]
+    auto rol = [](uint64_t v, int n) { return n ? (v << n) | (v >> (64 - n)) : v; };
+    for (int round = 0; round < 24; ++round) {
+        uint64_t c[5], d[5], b[25];
+        for (int x = 0; x < 5; ++x) c[x] = st[x] ^ st[x + 5] ^ st[x + 10] ^ st[x + 15] ^ st[x + 20];
+        for (int x = 0; x < 5; ++x) d[x] = c[(x + 4) % 5] ^ rol(c[(x + 1) % 5], 1);
+        for (int i = 0; i < 25; ++i) st[i] ^= d[i % 5];
+        for (int x = 0; x < 5; ++x) for (int y = 0; y < 5; ++y) b[y + 5 * ((2 * x + 3 * y) % 5)] = rol(st[x + 5 * y], ROT[x + 5 * y]);
+        for (int x = 0; x < 5; ++x) for (int y = 0; y < 5; ++y) st[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+        st[0] ^= RC[round];
+    }
+}
+// legacy Keccak-256 (Ethereum / Solidity keccak256): rate 136, padding 0x01 .. 0x80
+static void keccak256(const uint8_t* data, size_t len, uint8_t out[32]) {
+    uint64_t st[25] = {0};
+    std::vector<uint8_t> p(data, data + len);
+    p.push_back(0x01);
+    while (p.size() % 136) p.push_back(0);
+    p.back() |= 0x80;
+    for (size_t off = 0; off < p.size(); off += 136) {
+        for (int i = 0; i < 17; ++i) { uint64_t v = 0; for (int k = 7; k >= 0; --k) v = (v << 8) | p[off + 8 * i + k]; st[i] ^= v; }
+        keccak_f1600(st);
+    }
+    for (int i = 0; i < 4; ++i) for (int k = 0; k < 8; ++k) out[8 * i + k] = (uint8_t)(st[i] >> (8 * k));
+}
+extern "C" int32_t dvn_keccak256(const uint8_t* data, size_t len, uint8_t out[32]) {
+    if ((!data && len) || !out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    keccak256(data, len, out);
+    return DVN_OK;
+}
+static void fr_ext_to_be32(const u32* ext_words, uint8_t* out) {
+    u32 t[8], c[8];
+    memcpy(t, ext_words, 32);
+    fe_pack<FrCfg>(fe_canonical<FrCfg>(fe_mul<FrCfg>(fe_unpack<FrCfg>(t), fe_small<FrCfg>(32))), c);   // x*2^256 -> x
+    for (int i = 0; i < 8; ++i) {
+        const u32 w = c[7 - i];
+        out[4 * i] = (uint8_t)(w >> 24); out[4 * i + 1] = (uint8_t)(w >> 16); out[4 * i + 2] = (uint8_t)(w >> 8); out[4 * i + 3] = (uint8_t)w;
+    }
+}
+
+extern "C" int32_t dvn_r1cs_synthetic_committed(uint64_t seed, uint32_t n_constraints, uint32_t n_public, uint32_t n_committed, dvn_r1cs** out) {
+    if (!n_committed) return fail(DVN_ERR_INVALID_ARG, "n_committed must be positive");
+    return r1cs_synthetic<SuiteBn254>(seed, n_constraints, n_public, out, n_committed, 2);
+}
+
+// witness: the solver's assignment BEFORE the commitment is known (commitment wire and the constraints reading it are
+// placeholders; dvn_r1cs_witness of a committed instance returns exactly that).  commitment_out / pok_out: G1Affine images
+// (gnark Proof.Commitments[0], Proof.CommitmentPok); challenge_out: the commitment wire's value (Montgomery words).
+extern "C" int32_t dvn_groth16_prove_committed(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
+                                               const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32],
+                                               uint64_t commitment_out[8], uint64_t pok_out[8], uint64_t challenge_out[4]) {
+    typedef SuiteBn254 SU;
+    typedef FrCfg S;
+    typedef dvn_host::HG1 H1;
+    constexpr u32 EW = 8;
+    TRY(enter(ctx));
+    if (!pk || !witness || !r_mont || !s_mont || !proof_out || !commitment_out || !pok_out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    if (pk->suite != SU::SUITE) return fail(DVN_ERR_UNSUPPORTED, "committed proofs exist for BN254 keys only");
+    if (!pk->n_committed) return fail(DVN_ERR_INVALID_ARG, "the key has no commitment: use dvn_groth16_prove");
+    const HostKey<SU>& hk = *(const HostKey<SU>*)pk->hk;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    Blind<SU> bl(hk, r_mont, s_mont);
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(pk->d_w, witness, pk->m * EW * 4, (flags & 1) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    // (1) the commitment hint: two MSMs over the committed wires, in flight together
+    const u32* d_committed = pk->d_w + (size_t)pk->n_public * EW;
+    MsmLane *lc = nullptr, *lp = nullptr;
+    H1::X c, k;
+    TRY(SU::msm_submit_g1(ctx, pk->Basis, 0, pk->n_committed, d_committed, &lc));
+    int32_t rc = SU::msm_submit_g1(ctx, pk->BasisSigma, 0, pk->n_committed, d_committed, &lp);
+    if (rc != DVN_OK) { H1::X t; (void)SU::msm_collect_g1(ctx, lc, &t); return rc; }
+    rc = SU::msm_collect_g1(ctx, lc, &c);
+    const int32_t rc2 = SU::msm_collect_g1(ctx, lp, &k);
+    if (rc != DVN_OK) return rc;
+    TRY(rc2);
+    uint64_t j[12];
+    H1::write_jac(c, j); memcpy(commitment_out, j, 64); if (H1::is_inf(c)) memset(commitment_out, 0, 64);
+    H1::write_jac(k, j); memcpy(pok_out, j, 64); if (H1::is_inf(k)) memset(pok_out, 0, 64);
+    // challenge = keccak256(C.x || C.y || publicCommitted...) mod r
+    std::vector<uint8_t> buf(64 + 32 * pk->public_committed.size());
+    fp_ext_to_be32((const u32*)commitment_out, buf.data()); fp_ext_to_be32((const u32*)commitment_out + 8, buf.data() + 32);
+    for (size_t i = 0; i < pk->public_committed.size(); ++i) {
+        u32 wv[EW];
+        HIP_TRY(hipMemcpyAsync(wv, pk->d_w + (size_t)pk->public_committed[i] * EW, 32, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        fr_ext_to_be32(wv, buf.data() + 64 + 32 * i);
+    }
+    uint8_t hsh[32];
+    keccak256(buf.data(), buf.size(), hsh);
+    u32 cwv[EW], cext[EW];
+    for (int i = 0; i < 8; ++i) { const uint8_t* p = hsh + 4 * (7 - i); cwv[i] = ((u32)p[0] << 24) | ((u32)p[1] << 16) | ((u32)p[2] << 8) | (u32)p[3]; }
+    while (geq8(cwv, FR_MOD_W)) sub8(cwv, FR_MOD_W);
+    fr_to_ext_words<S>(fe_from_canonical<S>(fe_unpack<S>(cwv)), cext);
+    if (challenge_out) memcpy(challenge_out, cext, 32);
+    // the solver's last step: challenge into its wire, then the constraints that read it
+    HIP_TRY(hipMemcpyAsync(pk->d_w + (size_t)pk->commit_wire * EW, cext, 32, hipMemcpyHostToDevice, st));
+    k_r1cs_patch_rows<S><<<1, 64, 0, st>>>(pk->d_ptr[0], pk->d_idx[0], pk->d_coef[0], pk->d_ptr[1], pk->d_idx[1], pk->d_coef[1], pk->d_ptr[2], pk->d_idx[2],
+                                           pk->d_w, (u32)(pk->n_constraints - pk->tail), (u32)pk->n_constraints);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));                 // cext lives on this stack frame
+    MsmResults<SU> R;
+    TRY(groth16_device<SU>(ctx, pk, (const uint64_t*)pk->d_w, 1u | 2u, 0, 1, &R));
+    groth16_assemble<SU>(hk, R, bl, proof_out);
     return DVN_OK;
 }

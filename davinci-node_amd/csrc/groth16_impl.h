@@ -41,6 +41,10 @@ struct dvn_r1cs {
     u32 n_wires = 0, n_public = 0, n_constraints = 0;
     Csr m[3];                       // A, B, C by constraint row
     std::vector<u32> witness;       // n_wires x 8, gnark Montgomery words (synthetic instances only)
+    // one BSB22 commitment (0 = none): wire order [1, inputs, commitment wire, committed private wires, other private wires];
+    // only the last `tail` constraints read the commitment wire; public_committed = public wires hashed into the challenge
+    u32 commit_wire = 0, n_committed = 0, tail = 0;
+    std::vector<u32> public_committed;
 };
 struct dvn_groth16_pk {
     u32 log_n = 0;
@@ -55,6 +59,11 @@ struct dvn_groth16_pk {
     u32 *d_ptr[3] = {nullptr, nullptr, nullptr}, *d_idx[3] = {nullptr, nullptr, nullptr}, *d_coef[3] = {nullptr, nullptr, nullptr};
     u32 *d_w = nullptr, *d_abc = nullptr, *d_wA = nullptr, *d_wB = nullptr;   // per-proof buffers, allocated once
     float ms_h = 0, ms_msm = 0, ms_total = 0;
+    // BSB22 commitment (n_committed = 0: none): K covers the wires [k_first, m); Basis / BasisSigma the committed ones
+    size_t k_first = 0;
+    u32 commit_wire = 0, n_committed = 0, tail = 0;
+    std::vector<u32> public_committed;
+    dvn_points *Basis = nullptr, *BasisSigma = nullptr;
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -71,6 +80,22 @@ template <class S> __global__ void k_r1cs_matvec(const u32* __restrict__ ptr, co
     for (u32 k = ptr[r]; k < ptr[r + 1]; ++k)
         acc = fe_add<S>(acc, fe_mul<S>(ld_fr<S>(coef + (size_t)k * S::EW), ld_fr<S>(w + (size_t)idx[k] * S::EW)));
     st_fr<S>(acc, out + (size_t)r * S::EW);
+}
+// The solver's last step with a BSB22 commitment: once the challenge is in its wire, re-evaluate the constraints
+// [row_lo, row_hi) in order, w[C_row] = (A_row w)(B_row w) (C rows of the synthetic instance are one wire, coefficient 1).
+// One thread: O(tail) work.  c32 = 2^5 in internal form (the words are read as x * 2^-5, see k_r1cs_matvec).
+template <class S> __global__ void k_r1cs_patch_rows(const u32* __restrict__ pa, const u32* __restrict__ ia, const u32* __restrict__ ca,
+                                                     const u32* __restrict__ pb, const u32* __restrict__ ib, const u32* __restrict__ cb,
+                                                     const u32* __restrict__ pc, const u32* __restrict__ ic, u32* __restrict__ w, u32 row_lo, u32 row_hi) {
+    if (blockIdx.x || threadIdx.x) return;
+    u32 w32[S::EW] = {32u};
+    const Fe<S> c32 = fe_from_canonical<S>(fe_unpack<S>(w32));
+    for (u32 r = row_lo; r < row_hi; ++r) {
+        Fe<S> a = fe_zero<S>(), b = fe_zero<S>();
+        for (u32 k = pa[r]; k < pa[r + 1]; ++k) a = fe_add<S>(a, fe_mul<S>(ld_fr<S>(ca + (size_t)k * S::EW), ld_fr<S>(w + (size_t)ia[k] * S::EW)));
+        for (u32 k = pb[r]; k < pb[r + 1]; ++k) b = fe_add<S>(b, fe_mul<S>(ld_fr<S>(cb + (size_t)k * S::EW), ld_fr<S>(w + (size_t)ib[k] * S::EW)));
+        st_fr<S>(fe_mul<S>(fe_mul<S>(a, b), c32), w + (size_t)ic[pc[r]] * S::EW);
+    }
 }
 template <int EW> __global__ void k_gather_fr(const u32* __restrict__ src, const u32* __restrict__ idx, u32* __restrict__ dst, size_t count) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -186,9 +211,14 @@ template <class T> static int32_t dev_upload(T** d, const std::vector<T>& h) {
 // ------------------------------------------------------------------------------------------------------
 // synthetic R1CS (oracle/bn254_py.py SyntheticR1CS): rows (w[l1] + k*w[l2]) * w[r] = w[o], witness built forward
 // ------------------------------------------------------------------------------------------------------
-template <class SU> static int32_t r1cs_synthetic(uint64_t seed, uint32_t n_constraints, uint32_t n_public, dvn_r1cs** out) {
+// n_committed > 0: one BSB22 commitment (oracle/bn254_py.py SyntheticR1CSCommitted): the commitment wire follows the public
+// inputs, the first n_committed private wires are committed, only the last `tail` constraints read the commitment wire
+// (its value, and those constraints' outputs, are placeholders in cs->witness until the prover completes them).
+template <class SU> static int32_t r1cs_synthetic(uint64_t seed, uint32_t n_constraints, uint32_t n_public, dvn_r1cs** out,
+                                                  uint32_t n_committed = 0, uint32_t tail = 2) {
     typedef typename SU::FrC S;
     if (!out || n_public < 1) return fail(DVN_ERR_INVALID_ARG, "bad argument");
+    if (n_committed && n_constraints <= tail) return fail(DVN_ERR_INVALID_ARG, "need more than %u constraints", tail);
     dvn_r1cs* cs = new (std::nothrow) dvn_r1cs();
     if (!cs) return fail(DVN_ERR_OOM, "host allocation failed");
     cs->suite = SU::SUITE;
@@ -198,14 +228,26 @@ template <class SU> static int32_t r1cs_synthetic(uint64_t seed, uint32_t n_cons
     w.reserve((size_t)n_public + n_free + n_constraints);
     w.push_back(fe_one<S>());
     for (u32 i = 1; i < n_public; ++i) w.push_back(rng.template next_fr<S>(SU::r_words()));
-    for (u32 i = 0; i < n_free; ++i) w.push_back(rng.template next_fr<S>(SU::r_words()));
+    const u32 cw = n_committed ? n_public : 0xffffffffu;
+    if (n_committed) {
+        w.push_back(fe_zero<S>());                                   // the commitment wire closes the public section
+        cs->commit_wire = n_public; cs->n_committed = n_committed; cs->tail = tail;
+        if (n_public >= 4) cs->public_committed.push_back(3); else if (n_public >= 2) cs->public_committed.push_back(n_public - 1);
+    }
+    for (u32 i = 0; i < n_free + n_committed; ++i) w.push_back(rng.template next_fr<S>(SU::r_words()));
     for (int k = 0; k < 3; ++k) cs->m[k].ptr.push_back(0);
     auto push = [&](Csr& c, u32 wire, u64 coefv) { c.idx.push_back(wire); u32 t[S::EW]; fr_pack_internal<S>(fr_u64<S>(coefv), t); c.coef.insert(c.coef.end(), t, t + S::EW); };
     for (u32 j = 0; j < n_constraints; ++j) {
         const u64 mcur = w.size();
-        const u32 l1 = (u32)(rng.next() % mcur), l2 = (u32)(rng.next() % mcur);
+        u32 l1 = (u32)(rng.next() % mcur), l2 = (u32)(rng.next() % mcur);
         const u64 k = rng.next() % 7 + 1;
-        const u32 r_ = (u32)(rng.next() % mcur), o = (u32)mcur;
+        u32 r_ = (u32)(rng.next() % mcur);
+        const u32 o = (u32)mcur;
+        if (n_committed) {
+            if (l2 == cw) l2 = 0;
+            if (r_ == cw) r_ = 0;
+            l1 = (j >= n_constraints - tail) ? cw : (l1 == cw ? 0 : l1);
+        }
         Fe<S> val = fe_mul<S>(fe_add<S>(w[l1], fe_mul<S>(fr_u64<S>(k), w[l2])), w[r_]);
         w.push_back(val);
         if (l1 != l2) { push(cs->m[0], l1, 1); push(cs->m[0], l2, k); } else push(cs->m[0], l1, 1 + k);
@@ -213,7 +255,7 @@ template <class SU> static int32_t r1cs_synthetic(uint64_t seed, uint32_t n_cons
         push(cs->m[2], o, 1);
         for (int q = 0; q < 3; ++q) cs->m[q].ptr.push_back((u32)cs->m[q].idx.size());
     }
-    cs->n_wires = (u32)w.size(); cs->n_public = n_public; cs->n_constraints = n_constraints;
+    cs->n_wires = (u32)w.size(); cs->n_public = n_public + (n_committed ? 1 : 0); cs->n_constraints = n_constraints;
     cs->witness.resize((size_t)cs->n_wires * S::EW);
     for (size_t i = 0; i < w.size(); ++i) fr_to_ext_words<S>(w[i], cs->witness.data() + i * S::EW);
     *out = cs;
@@ -275,8 +317,10 @@ template <class SU> static int32_t groth16_setup(dvn_ctx* ctx, const dvn_r1cs* c
     if (rc) { delete pk; return rc; }
     std::unique_lock<std::mutex> lk(ctx->mu);
     SplitMix rng(seed);
-    Fe<S> tw[5];
-    for (int i = 0; i < 5; ++i) { tw[i] = rng.template next_fr<S>(SU::r_words()); if (fe_is_zero<S>(tw[i])) tw[i] = fe_one<S>(); }
+    Fe<S> tw[6];
+    for (int i = 0; i < (cs->n_committed ? 6 : 5); ++i) { tw[i] = rng.template next_fr<S>(SU::r_words()); if (fe_is_zero<S>(tw[i])) tw[i] = fe_one<S>(); }
+    pk->k_first = (size_t)cs->n_public + cs->n_committed;
+    pk->commit_wire = cs->commit_wire; pk->n_committed = cs->n_committed; pk->tail = cs->tail; pk->public_committed = cs->public_committed;
     const Fe<S> tau = tw[0], alpha = tw[1], beta = tw[2], delta = tw[4];
     const Fe<S> one = fe_one<S>(), dinv = fe_inv<S>(delta);
     const Fe<S> ztau = fe_sub<S>(fe_pow_u64<S>(tau, n), one);
@@ -322,10 +366,10 @@ template <class SU> static int32_t groth16_setup(dvn_ctx* ctx, const dvn_r1cs* c
             TRY(dev_upload(&pk->d_ptr[q], r.ptr)); TRY(dev_upload(&pk->d_idx[q], r.idx)); TRY(dev_upload(&pk->d_coef[q], r.coef));
         }
         // K (private wires) and Z (bit-reversed)
-        const size_t nk = m - cs->n_public;
+        const size_t nk = m - pk->k_first;
         HIP_TRY(hipMalloc((void**)&d_k, (nk ? nk : 1) * EB));
         HIP_TRY(hipMalloc((void**)&d_z, n * EB));
-        if (nk) k_key_k<S><<<(unsigned)((nk + 63) / 64), 64, 0, st>>>(d_t[0], d_t[1], d_t[2], d_consts + 3 * EW, d_k, cs->n_public, (u32)nk);
+        if (nk) k_key_k<S><<<(unsigned)((nk + 63) / 64), 64, 0, st>>>(d_t[0], d_t[1], d_t[2], d_consts + 3 * EW, d_k, (u32)pk->k_first, (u32)nk);
         k_key_z<S><<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_z, d_consts + 6 * EW, log_n);
         HIP_TRY(hipGetLastError());
         // infinity filtering of A and B (gnark's InfinityA / InfinityB)
@@ -350,6 +394,26 @@ template <class SU> static int32_t groth16_setup(dvn_ctx* ctx, const dvn_r1cs* c
         TRY((fixed_base_points<G1, S>(ctx, g1, d_cmp, pk->nB, 1, &pk->B)));
         TRY((fixed_base_points<G2, S>(ctx, g2, d_cmp, pk->nB, 2, &pk->B2)));
         TRY((fixed_base_points<G1, S>(ctx, g1, d_k, nk, 1, &pk->K)));
+        if (cs->n_committed) {
+            // commitment key (gnark groth16 Setup + pedersen.Setup): Basis_i = [(beta A_i + alpha B_i + C_i)(tau) / gamma]G1 for the
+            // committed wires -- the commitment is added to the gamma-paired public-input accumulator by the verifier
+            // (/root/reference/config/statetransition_vkey.sol:412-416) -- and BasisExpSigma_i = sigma * Basis_i
+            const Fe<S> ginv = fe_inv<S>(tw[3]);
+            u32 hb[6 * EW];
+            fr_pack_internal<S>(alpha, hb); fr_pack_internal<S>(beta, hb + EW); fr_pack_internal<S>(ginv, hb + 2 * EW);
+            fr_pack_internal<S>(alpha, hb + 3 * EW); fr_pack_internal<S>(beta, hb + 4 * EW); fr_pack_internal<S>(fe_mul<S>(ginv, tw[5]), hb + 5 * EW);
+            u32* d_bc = nullptr;
+            HIP_TRY(hipMalloc((void**)&d_bc, sizeof(hb) + (size_t)cs->n_committed * EB));
+            u32* d_bs = d_bc + 6 * EW;
+            hipError_t e = hipMemcpy(d_bc, hb, sizeof(hb), hipMemcpyHostToDevice);
+            int32_t rc2 = e == hipSuccess ? DVN_OK : fail(DVN_ERR_DEVICE, "commitment key upload failed: %s", hipGetErrorString(e));
+            for (int which = 0; which < 2 && rc2 == DVN_OK; ++which) {
+                k_key_k<S><<<(cs->n_committed + 63) / 64, 64, 0, st>>>(d_t[0], d_t[1], d_t[2], d_bc + 3 * which * EW, d_bs, cs->n_public, cs->n_committed);
+                rc2 = fixed_base_points<G1, S>(ctx, g1, d_bs, cs->n_committed, 1, which ? &pk->BasisSigma : &pk->Basis);
+            }
+            (void)hipFree(d_bc);
+            TRY(rc2);
+        }
         TRY((fixed_base_points<G1, S>(ctx, g1, d_z, n, 1, &pk->Z)));
         // per-proof buffers
         HIP_TRY(hipMalloc((void**)&pk->d_w, m * EB));
@@ -405,7 +469,8 @@ template <class SU> static int32_t groth16_device(dvn_ctx* ctx, dvn_groth16_pk* 
     };
     auto body = [&]() -> int32_t {
         HIP_TRY(hipEventRecord(e0, st));
-        HIP_TRY(hipMemcpyAsync(pk->d_w, witness, m * EB, (flags & 1) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        if (!(flags & 2))      // flags & 2: the (completed) witness already sits in pk->d_w (committed proofs)
+            HIP_TRY(hipMemcpyAsync(pk->d_w, witness, m * EB, (flags & 1) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
         // (4) filter the wire vector by InfinityA / InfinityB
         if (pk->nA) k_gather_fr<S::EW><<<(unsigned)((pk->nA + 255) / 256), 256, 0, st>>>(pk->d_w, pk->d_idxA, pk->d_wA, pk->nA);
         if (pk->nB) k_gather_fr<S::EW><<<(unsigned)((pk->nB + 255) / 256), 256, 0, st>>>(pk->d_w, pk->d_idxB, pk->d_wB, pk->nB);
@@ -416,7 +481,7 @@ template <class SU> static int32_t groth16_device(dvn_ctx* ctx, dvn_groth16_pk* 
         TRY(submit_g2(pk->B2, pk->nB, pk->d_wB, &l2));
         TRY(submit_g1(pk->A, pk->nA, pk->d_wA, &lA));
         TRY(submit_g1(pk->B, pk->nB, pk->d_wB, &lB));
-        TRY(submit_g1(pk->K, m - pk->n_public, pk->d_w + pk->n_public * EW, &lK));
+        TRY(submit_g1(pk->K, m - pk->k_first, pk->d_w + pk->k_first * EW, &lK));
         // ... while the main stream runs (1) the "solve" a = A w, b = B w, c = C w (zero padded to the domain size) and
         // (3) h = computeH(a, b, c), which stays on the device as the scalar vector of the Z MSM
         HIP_TRY(hipMemsetAsync(pk->d_abc, 0, 3 * n * EB, st));

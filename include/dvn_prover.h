@@ -292,6 +292,21 @@ int32_t dvn_bw6761_groth16_setup(dvn_ctx* ctx, const dvn_r1cs* cs, uint64_t seed
 int32_t dvn_bw6761_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
                                  const uint64_t r_mont[6], const uint64_t s_mont[6], uint64_t proof_out[72]);
 
+/* ---- Groth16 with one BSB22 commitment: the statetransition shape (8 public inputs + 1 commitment wire,
+ * /root/reference/config/statetransition_vkey.sol:97-114; gnark Prove steps (1)-(2) of SURVEY.md row a10, row a14).
+ * dvn_r1cs_synthetic_committed: as dvn_r1cs_synthetic plus a commitment wire after the n_public public wires and
+ * n_committed committed private wires; dvn_r1cs_info then reports n_public + 1 public wires.  dvn_groth16_setup builds
+ * the commitment key (Basis = K / gamma over the committed wires, BasisExpSigma = sigma * Basis).
+ * dvn_groth16_prove_committed: Commitment and CommitmentPok (two MSMs), the challenge
+ * keccak256(C.x || C.y || publicCommitted) mod r that the reference's Solidity verifier recomputes
+ * (statetransition_vkey.sol:659-676), the completion of the witness, then the proof as dvn_groth16_prove.
+ * Together with dvn_groth16_proof_abi_encode this yields the calldata of solidity/solidity.go:85-116. */
+int32_t dvn_r1cs_synthetic_committed(uint64_t seed, uint32_t n_constraints, uint32_t n_public, uint32_t n_committed, dvn_r1cs** out);
+int32_t dvn_groth16_prove_committed(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
+                                    const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32],
+                                    uint64_t commitment_out[8], uint64_t pok_out[8], uint64_t challenge_out[4]);
+int32_t dvn_keccak256(const uint8_t* data, size_t len, uint8_t out[32]);     /* host only: Solidity's keccak256 */
+
 /* ---- Blob KZG on BLS12-381 (EIP-4844 / EIP-7594) ------------------------------------------------
  * The step before every state-transition proof, /root/reference/crypto/blobs/blob.go:40-90 (BlobEvalData.Set):
  *   dvn_kzg_blob_to_commitment   replaces Blob.ComputeCommitment   /root/reference/types/blobs.go:88-95

@@ -553,3 +553,138 @@ def groth16_expected_from_trapdoor(cs: SyntheticR1CS, trap, dom: Domain, r: int,
     priv = sum(w[cs.n_public + i] * k for i, k in enumerate(trap["K"])) % R
     krs = (priv + h_tau * z_tau % R * pow(delta, -1, R) + s * ar + r * bs - r * s % R * delta) % R
     return {"Ar": g1_mul(G1_GEN, ar), "Bs": g2_mul(G2_GEN, bs), "Krs": g1_mul(G1_GEN, krs)}
+
+
+# ------------------------------------------------------------------------------------------------------
+# BSB22 commitment: the statetransition circuit has exactly one
+# (/root/reference/solidity/solidity.go:57-65; 8 public inputs + 1 commitment wire = PUB_0..PUB_8,
+# /root/reference/config/statetransition_vkey.sol:97-114).  What the reference tree itself pins:
+#   challenge  = keccak256(C.x || C.y || publicCommitted...) mod r            statetransition_vkey.sol:659-676
+#   vk_x       = CONSTANT + C + sum_i input_i PUB_i + challenge PUB_8         statetransition_vkey.sol:393-520
+#   PoK check  e(C, GSigmaNeg) e(pok, G) = 1                                  statetransition_vkey.sol:678-700
+# so C = [sum_committed w_i (beta A_i + alpha B_i + C_i)(tau) / gamma]G1 (it is added to the gamma-paired accumulator)
+# and pok = sigma C for the sigma with GSigmaNeg = -sigma G.
+# ------------------------------------------------------------------------------------------------------
+_KECCAK_RC = [0x0000000000000001, 0x0000000000008082, 0x800000000000808A, 0x8000000080008000, 0x000000000000808B, 0x0000000080000001,
+              0x8000000080008081, 0x8000000000008009, 0x000000000000008A, 0x0000000000000088, 0x0000000080008009, 0x000000008000000A,
+              0x000000008000808B, 0x800000000000008B, 0x8000000000008089, 0x8000000000008003, 0x8000000000008002, 0x8000000000000080,
+              0x000000000000800A, 0x800000008000000A, 0x8000000080008081, 0x8000000000008080, 0x0000000080000001, 0x8000000080008008]
+_KECCAK_ROT = [[0, 36, 3, 41, 18], [1, 44, 10, 45, 2], [62, 6, 43, 15, 61], [28, 55, 25, 21, 56], [27, 20, 39, 8, 14]]
+
+
+def _keccak_f(st):
+    M = (1 << 64) - 1
+    rol = lambda v, n: ((v << n) | (v >> (64 - n))) & M if n else v
+    for rc in _KECCAK_RC:
+        c = [st[x][0] ^ st[x][1] ^ st[x][2] ^ st[x][3] ^ st[x][4] for x in range(5)]
+        d = [c[(x - 1) % 5] ^ rol(c[(x + 1) % 5], 1) for x in range(5)]
+        st = [[st[x][y] ^ d[x] for y in range(5)] for x in range(5)]
+        b = [[0] * 5 for _ in range(5)]
+        for x in range(5):
+            for y in range(5):
+                b[y][(2 * x + 3 * y) % 5] = rol(st[x][y], _KECCAK_ROT[x][y])
+        st = [[b[x][y] ^ ((~b[(x + 1) % 5][y]) & b[(x + 2) % 5][y]) for y in range(5)] for x in range(5)]
+        st[0][0] ^= rc
+    return st
+
+
+def keccak256(data: bytes) -> bytes:
+    """Legacy Keccak-256 (Ethereum's; pad 0x01 .. 0x80, rate 136), what Solidity's keccak256 computes."""
+    rate = 136
+    p = bytearray(data) + b"\x01" + bytes((-len(data) - 2) % rate) + b"\x80" if (len(data) + 1) % rate else bytearray(data) + b"\x81"
+    st = [[0] * 5 for _ in range(5)]
+    for off in range(0, len(p), rate):
+        for i in range(rate // 8):
+            st[i % 5][i // 5] ^= int.from_bytes(p[off + 8 * i:off + 8 * i + 8], "little")
+        st = _keccak_f(st)
+    return b"".join(st[i % 5][i // 5].to_bytes(8, "little") for i in range(4))
+
+
+class SyntheticR1CSCommitted:
+    """SyntheticR1CS with ONE BSB22 commitment.  Wire order as gnark's: [1, public inputs, commitment wire (public
+    section), private ...]; the first n_committed private wires are the committed ones; public_committed lists the
+    public wires hashed into the challenge (statetransition: the third input, vkey.sol:665).  Only the last `tail`
+    constraints read the commitment wire, so completing the witness once the commitment is known is O(tail)."""
+
+    def __init__(self, n_constraints: int, n_public: int, n_committed: int, seed: int, tail: int = 2):
+        assert n_public >= 1 and n_constraints > tail and n_committed >= 1
+        rng = SplitMix64(seed)
+        self.n_inputs = n_public                       # constant + public inputs
+        self.commit_wire = n_public
+        self.n_public = n_public + 1                   # public section incl. the commitment wire
+        self.n_committed, self.tail, self.n_constraints = n_committed, tail, n_constraints
+        self.committed = list(range(self.n_public, self.n_public + n_committed))
+        self.public_committed = [3] if n_public >= 4 else ([n_public - 1] if n_public >= 2 else [])
+        w = [1] + [rng.next_fr() for _ in range(n_public - 1)] + [0]
+        w += [rng.next_fr() for _ in range(4 + n_committed)]
+        self.A, self.B, self.C = [], [], []
+        cw = self.commit_wire
+        for j in range(n_constraints):
+            m = len(w)
+            l1, l2 = rng.next() % m, rng.next() % m
+            k = rng.next() % 7 + 1
+            r_ = rng.next() % m
+            l2 = 0 if l2 == cw else l2
+            r_ = 0 if r_ == cw else r_
+            l1 = cw if j >= n_constraints - tail else (0 if l1 == cw else l1)
+            w.append(((w[l1] + k * w[l2]) * w[r_]) % R)
+            self.A.append([(l1, 1), (l2, k)] if l1 != l2 else [(l1, (1 + k) % R)])
+            self.B.append([(r_, 1)])
+            self.C.append([(m, 1)])
+        self.witness = w                               # commitment wire = 0, tail outputs computed with it: incomplete
+        self.n_wires = len(w)
+
+    def complete(self, challenge: int):
+        """The solver's last step: commitment wire := challenge, then the constraints that read it, in order."""
+        w = list(self.witness)
+        w[self.commit_wire] = challenge % R
+        for j in range(self.n_constraints - self.tail, self.n_constraints):
+            a = sum(c * w[i] for i, c in self.A[j]) % R
+            b = sum(c * w[i] for i, c in self.B[j]) % R
+            w[self.C[j][0][0]] = a * b % R
+        return w
+
+
+def commitment_challenge(cpt, public_values):
+    """statetransition_vkey.sol:659-676: keccak256(abi.encodePacked(C.x, C.y, publicAndCommitmentCommitted)) % R."""
+    x, y = (0, 0) if cpt is None else cpt
+    data = x.to_bytes(32, "big") + y.to_bytes(32, "big") + b"".join(v.to_bytes(32, "big") for v in public_values)
+    return int.from_bytes(keccak256(data), "big") % R
+
+
+def groth16_committed_expected(cs: SyntheticR1CSCommitted, seed: int, r: int, s: int):
+    """Closed-form proof with one commitment from the trapdoor (tau, alpha, beta, gamma, delta, sigma drawn in that order
+    from SplitMix64(seed)): O(n) field work + 5 fixed-base multiplications.  Returns the proof points, the completed
+    witness and the exponents (so a test can check the verifier's equation in the exponent)."""
+    rng = SplitMix64(seed)
+    tau, alpha, beta, gamma, delta, sigma = (rng.next_fr() or 1 for _ in range(6))
+    dom = Domain(cs.n_constraints)
+    n = dom.n
+    L = lagrange_at(dom, tau)
+    m = cs.n_wires
+    At, Bt, Ct = [0] * m, [0] * m, [0] * m
+    for rows, acc in ((cs.A, At), (cs.B, Bt), (cs.C, Ct)):
+        for j, row in enumerate(rows):
+            for i, c in row:
+                acc[i] = (acc[i] + c * L[j]) % R
+    t = [(beta * At[i] + alpha * Bt[i] + Ct[i]) % R for i in range(m)]
+    ginv, dinv = pow(gamma, -1, R), pow(delta, -1, R)
+    cexp = sum(cs.witness[i] * t[i] for i in cs.committed) % R * ginv % R
+    cpt = g1_mul(G1_GEN, cexp)
+    ch = commitment_challenge(cpt, [cs.witness[i] for i in cs.public_committed])
+    w = cs.complete(ch)
+    a_tau = sum(wi * v for wi, v in zip(w, At)) % R
+    b_tau = sum(wi * v for wi, v in zip(w, Bt)) % R
+    c_tau = sum(wi * v for wi, v in zip(w, Ct)) % R
+    z_tau = (pow(tau, n, R) - 1) % R
+    h_tau = (a_tau * b_tau - c_tau) * pow(z_tau, -1, R) % R
+    ar = (alpha + a_tau + r * delta) % R
+    bs = (beta + b_tau + s * delta) % R
+    first_k = cs.n_public + cs.n_committed
+    priv = sum(w[i] * t[i] for i in range(first_k, m)) % R * dinv % R
+    krs = (priv + h_tau * z_tau % R * dinv + s * ar + r * bs - r * s % R * delta) % R
+    vkx = (sum(w[i] * t[i] for i in range(cs.n_public)) % R * ginv + cexp) % R     # CONSTANT + inputs + challenge wire, + C
+    return {"Ar": g1_mul(G1_GEN, ar), "Bs": g2_mul(G2_GEN, bs), "Krs": g1_mul(G1_GEN, krs), "Commitment": cpt,
+            "CommitmentPok": g1_mul(G1_GEN, sigma * cexp % R), "challenge": ch, "witness": w,
+            "exponents": {"ar": ar, "bs": bs, "krs": krs, "vkx": vkx, "alpha": alpha, "beta": beta, "gamma": gamma, "delta": delta,
+                          "sigma": sigma, "cexp": cexp}}

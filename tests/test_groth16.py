@@ -132,3 +132,92 @@ def test_groth16_sharded_by_rows_recombines(ctx, pkg, opy, orc):
     with pytest.raises(pkg.DvnError):
         key2.prove_shard(cs2.witness(), 0, 2)
     key2.free(); cs2.free(); ctx.free(dw); key.free(); cs.free()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# One BSB22 commitment: the statetransition shape (8 public inputs + 1 commitment wire).
+# What the reference tree pins is restated in oracle/bn254_py.py (challenge formula, where the commitment enters the
+# verifier's accumulator, the PoK relation): config/statetransition_vkey.sol:393-416,659-700.
+# ---------------------------------------------------------------------------------------------------------------------
+def test_keccak256_known_answers(pkg, opy):
+    import ctypes as C
+    import hashlib
+    L = pkg.load_library()
+    def lib(b):
+        out = C.create_string_buffer(32)
+        assert L.dvn_keccak256(b, len(b), out) == 0
+        return out.raw
+    kat = {b"": "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470",
+           b"abc": "4e03657aea45a94fc7d47ba826c8d667c0d1e6e33a64a036ec44f58fa12d6c45"}
+    for msg, h in kat.items():
+        assert opy.keccak256(msg).hex() == h and lib(msg).hex() == h
+    for n in (1, 55, 96, 135, 136, 137, 271, 272, 273, 1000):            # across block boundaries: library == oracle
+        m = bytes((7 * i + n) & 0xFF for i in range(n))
+        assert lib(m) == opy.keccak256(m)
+    # the oracle's permutation is the SHA-3 one: with SHA-3's domain bits (pad 0x06) it reproduces hashlib.sha3_256
+    def sha3_with_oracle_permutation(data):
+        rate = 136
+        p = bytearray(data) + b"\x06" + bytes((-len(data) - 2) % rate) + b"\x80" if (len(data) + 1) % rate else bytearray(data) + b"\x86"
+        st = [[0] * 5 for _ in range(5)]
+        for off in range(0, len(p), rate):
+            for i in range(rate // 8):
+                st[i % 5][i // 5] ^= int.from_bytes(p[off + 8 * i:off + 8 * i + 8], "little")
+            st = opy._keccak_f(st)
+        return b"".join(st[i % 5][i // 5].to_bytes(8, "little") for i in range(4))
+    for n in (0, 3, 135, 136, 500):
+        assert sha3_with_oracle_permutation(b"q" * n) == hashlib.sha3_256(b"q" * n).digest()
+
+
+def test_committed_r1cs_matches_oracle_and_verifier_equation(pkg, opy):
+    """Host only: the committed synthetic instance equals the oracle's, and the oracle's closed-form proof satisfies the
+    verifier's equation A*B = alpha*beta + gamma*(vk_x + C) + delta*Krs in the exponent (statetransition_vkey.sol:393-416:
+    the commitment is ADDED to the public-input accumulator that is paired with gamma)."""
+    o = opy
+    cs = pkg.R1CS(7, 50, 9, n_committed=5)
+    ref = o.SyntheticR1CSCommitted(50, 9, 5, 7)
+    assert (cs.n_wires, cs.n_public, cs.n_constraints) == (ref.n_wires, 10, 50)
+    assert [o.from_mont(o.from_limbs(r), R) for r in cs.witness()] == ref.witness
+    cs.free()
+    e = o.groth16_committed_expected(ref, 3, 1234, 5678)
+    x = e["exponents"]
+    assert x["ar"] * x["bs"] % R == (x["alpha"] * x["beta"] + x["gamma"] * x["vkx"] + x["delta"] * x["krs"]) % R
+    w = e["witness"]
+    assert w[ref.commit_wire] == e["challenge"] != 0
+    for A, B, Cc in zip(ref.A, ref.B, ref.C):
+        assert sum(c * w[i] for i, c in A) * sum(c * w[i] for i, c in B) % R == sum(c * w[i] for i, c in Cc) % R
+    assert e["CommitmentPok"] == o.g1_mul(e["Commitment"], x["sigma"])           # e(C, -sigma G) e(pok, G) = 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_constraints,n_public,n_committed", [(50, 9, 5), (1000, 9, 64), (1 << 12, 9, 700), ((1 << 14) - 3, 4, 1), (1 << 16, 9, 1 << 12)])
+def test_groth16_with_commitment_trapdoor_identity(ctx, pkg, opy, n_constraints, n_public, n_committed):
+    o = opy
+    cs = pkg.R1CS(7, n_constraints, n_public, n_committed=n_committed)
+    key = pkg.Groth16Key(ctx, cs, 3)
+    ref = o.SyntheticR1CSCommitted(n_constraints, n_public, n_committed, 7)
+    assert key.sizes["K"] == ref.n_wires - (n_public + 1) - n_committed
+    for r, s in ((1234567, 7654321), (0, 0)):
+        want = o.groth16_committed_expected(ref, 3, r, s)
+        got = key.prove_committed(cs.witness(), mont(o, r), mont(o, s))
+        assert list(got["Commitment"]) == o.g1_to_limbs(want["Commitment"])
+        assert list(got["CommitmentPok"]) == o.g1_to_limbs(want["CommitmentPok"])
+        assert list(got["challenge"]) == o.limbs(o.to_mont(want["challenge"], R))
+        assert list(got["Ar"]) == o.g1_to_limbs(want["Ar"])
+        assert list(got["Bs"]) == o.g2_to_limbs(want["Bs"])
+        assert list(got["Krs"]) == o.g1_to_limbs(want["Krs"])
+    # device-resident witness, and the calldata image of solidity/solidity.go:85-116 with the commitment filled in
+    d = ctx.to_device(cs.witness())
+    got2 = key.prove_committed(d, mont(o, 1234567), mont(o, 7654321))
+    want = o.groth16_committed_expected(ref, 3, 1234567, 7654321)
+    assert list(got2["Krs"]) == o.g1_to_limbs(want["Krs"])
+    out = np.zeros(384, dtype=np.uint8)
+    proof = np.concatenate([got2["Ar"], got2["Bs"], got2["Krs"]])
+    assert pkg.load_library().dvn_groth16_proof_abi_encode(proof.ctypes.data, got2["Commitment"].ctypes.data, got2["CommitmentPok"].ctypes.data, out.ctypes.data) == 0
+    words = [int.from_bytes(bytes(out[32 * i:32 * i + 32]), "big") for i in range(12)]
+    assert words[8:10] == list(want["Commitment"]) and words[10:12] == list(want["CommitmentPok"])
+    # a key without commitment refuses the committed entry point, and vice versa the plain prover ignores nothing silently
+    ctx.free(d); key.free(); cs.free()
+    cs0 = pkg.R1CS(7, 100, 9); key0 = pkg.Groth16Key(ctx, cs0, 3)
+    with pytest.raises(pkg.DvnError):
+        key0.prove_committed(cs0.witness(), mont(o, 1), mont(o, 2))
+    key0.free(); cs0.free()
