@@ -227,6 +227,27 @@ def main():
         ctx.free(dw); key.free(); cs.free()
     if rank == 0 and world == 1 and not args.no_extras:
         extras = {}
+        # config 2 (2^20) and the witness-like scalar mixture of SURVEY.md §8d (40 % zero, 25 % one, 25 % < 2^64, 10 % uniform),
+        # same point set, three MSMs in flight as in the timed region
+        def msm_rate(nn, dscal, reps=12):
+            tk = []
+            t0 = None
+            for i in range(reps + 3):
+                if i == 3:
+                    ctx.synchronize(); t0 = time.perf_counter()
+                tk.append(ctx.msm_g1_submit(pts, dscal, n=nn))
+                if len(tk) == 3:
+                    ctx.msm_g1_collect(tk.pop(0))
+            while tk:
+                ctx.msm_g1_collect(tk.pop(0))
+            dt = (time.perf_counter() - t0) / reps
+            return {"ms_per_msm": round(dt * 1e3, 4), "Mscalar_per_s": round(nn / dt / 1e6, 1)}
+        if args.log_n == 22:
+            dwit = ctx.synthetic_scalars(1, 1, n)
+            extras["msm_g1_2^20_uniform"] = msm_rate(1 << 20, scal_dev)
+            extras["msm_g1_2^20_witness_like"] = msm_rate(1 << 20, dwit)
+            extras["msm_g1_2^22_witness_like"] = msm_rate(n, dwit)
+            ctx.free(dwit)
         # config 3: Fr NTT 2^24 forward (DIF) + inverse (DIT), data resident in HBM; 64 B per element per transform
         ln = 24
         dom = ctx.domain(ln)
