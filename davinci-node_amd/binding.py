@@ -126,6 +126,8 @@ def load_library():
         "dvn_kzg_blob_to_commitment": (i32, [vp, vp, vp, vp]),
         "dvn_kzg_compute_proof": (i32, [vp, vp, vp, vp, vp, vp]),
         "dvn_kzg_compute_cell_proofs": (i32, [vp, vp, vp, vp]),
+        "dvn_kzg_compute_blob_proof": (i32, [vp, vp, vp, vp, vp]),
+        "dvn_sha256": (i32, [vp, sz, vp]),
         "dvn_kzg_evaluate_barycentric": (i32, [vp, vp, vp, vp, vp]),
         "dvn_r1cs_curve": (i32, [vp]),
         "dvn_bw6761_points_upload": (i32, [vp, C.c_int, vp, sz, C.POINTER(vp)]),
@@ -172,7 +174,7 @@ EXPORTED_SYMBOLS = [
     "dvn_bls12381_r1cs_synthetic", "dvn_bls12381_groth16_setup", "dvn_bls12381_groth16_prove", "dvn_r1cs_curve",
     "dvn_r1cs_synthetic_committed", "dvn_groth16_prove_committed", "dvn_keccak256",
     "dvn_kzg_setup_load", "dvn_kzg_setup_free", "dvn_kzg_blob_to_commitment", "dvn_kzg_compute_proof", "dvn_kzg_compute_cell_proofs",
-    "dvn_kzg_evaluate_barycentric",
+    "dvn_kzg_evaluate_barycentric", "dvn_kzg_compute_blob_proof", "dvn_sha256",
     "dvn_bw6761_points_upload", "dvn_bw6761_points_synthetic", "dvn_bw6761_points_download", "dvn_bw6761_scalars_synthetic", "dvn_bw6761_msm",
     "dvn_bw6761_ntt_domain", "dvn_bw6761_ntt", "dvn_bw6761_groth16_compute_h",
     "dvn_bw6761_r1cs_synthetic", "dvn_bw6761_groth16_setup", "dvn_bw6761_groth16_prove",
@@ -692,6 +694,23 @@ class KzgSetup:
         out = C.create_string_buffer(128 * 48)
         self.ctx._chk(self.ctx.L.dvn_kzg_compute_cell_proofs(self.ctx.h, self.h, self._blob(blob), out))
         return [out.raw[48 * k:48 * k + 48] for k in range(128)]
+
+    def compute_blob_proof(self, blob: bytes, commitment: bytes) -> bytes:
+        """Blob.ComputeBlobProof (types/blobs.go:108-117): does not verify that the commitment belongs to the blob."""
+        if len(commitment) != 48:
+            raise ValueError("commitment must be 48 bytes")
+        out = C.create_string_buffer(48)
+        self.ctx._chk(self.ctx.L.dvn_kzg_compute_blob_proof(self.ctx.h, self.h, self._blob(blob), bytes(commitment), out))
+        return out.raw
+
+    def compute_commitment_and_proof(self, blob: bytes):
+        """Blob.ComputeCommitmentAndProof (types/blobs.go:138-148): Version 0 sidecar material."""
+        c = self.compute_commitment(blob)
+        return c, self.compute_blob_proof(blob, c)
+
+    def compute_commitment_and_cell_proofs(self, blob: bytes):
+        """Blob.ComputeCommitmentAndCellProofs (types/blobs.go:152-162): Version 1 sidecar material."""
+        return self.compute_commitment(blob), self.compute_cell_proofs(blob)
 
     def evaluate_barycentric(self, blob: bytes, z: int) -> int:
         y = C.create_string_buffer(32)

@@ -443,6 +443,66 @@ extern "C" int32_t dvn_kzg_compute_proof(dvn_ctx* ctx, const dvn_kzg_setup* s, c
     return kzg_commit(ctx, s, s->lagrange_brp, s->tab_lagrange, s->c_single, kzg::N, s->d_q, 1, proof);
 }
 
+// ---- SHA-256 (host): the Fiat-Shamir challenge of compute_blob_kzg_proof --------------------------------------------------
+static void kzg_sha256(const uint8_t* data, size_t len, uint8_t out[32]) {
+    static const u32 K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+        0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+        0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+        0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    u32 h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    std::vector<uint8_t> p(data, data + len);
+    p.push_back(0x80);
+    while (p.size() % 64 != 56) p.push_back(0);
+    const u64 bits = (u64)len * 8;
+    for (int i = 7; i >= 0; --i) p.push_back((uint8_t)(bits >> (8 * i)));
+    auto ror = [](u32 v, int n) { return (v >> n) | (v << (32 - n)); };
+    for (size_t off = 0; off < p.size(); off += 64) {
+        u32 w[64];
+        for (int i = 0; i < 16; ++i) w[i] = ((u32)p[off + 4 * i] << 24) | ((u32)p[off + 4 * i + 1] << 16) | ((u32)p[off + 4 * i + 2] << 8) | p[off + 4 * i + 3];
+        for (int i = 16; i < 64; ++i) {
+            const u32 s0 = ror(w[i - 15], 7) ^ ror(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = ror(w[i - 2], 17) ^ ror(w[i - 2], 19) ^ (w[i - 2] >> 10);
+            w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+        }
+        u32 a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+        for (int i = 0; i < 64; ++i) {
+            const u32 t1 = hh + (ror(e, 6) ^ ror(e, 11) ^ ror(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+            const u32 t2 = (ror(a, 2) ^ ror(a, 13) ^ ror(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+            hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+        h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    }
+    for (int i = 0; i < 8; ++i) { out[4 * i] = (uint8_t)(h[i] >> 24); out[4 * i + 1] = (uint8_t)(h[i] >> 16); out[4 * i + 2] = (uint8_t)(h[i] >> 8); out[4 * i + 3] = (uint8_t)h[i]; }
+}
+extern "C" int32_t dvn_sha256(const uint8_t* data, size_t len, uint8_t out[32]) {
+    if ((!data && len) || !out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    kzg_sha256(data, len, out);
+    return DVN_OK;
+}
+
+// Blob.ComputeBlobProof (/root/reference/types/blobs.go:108-117, gethkzg.ComputeBlobProof): EIP-4844 compute_blob_kzg_proof --
+// the opening proof at the Fiat-Shamir point z = sha256("FSBLOBVERIFY_V1_" || uint128_be(4096) || blob || commitment) mod r
+// (compute_challenge).  Like the reference's method it does not check that the commitment belongs to the blob.
+extern "C" int32_t dvn_kzg_compute_blob_proof(dvn_ctx* ctx, const dvn_kzg_setup* s, const uint8_t* blob, const uint8_t commitment[48], uint8_t proof[48]) {
+    TRY(enter(ctx));
+    if (!s || !blob || !commitment || !proof) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    std::vector<uint8_t> buf(32 + (size_t)kzg::N * 32 + 48, 0);
+    memcpy(buf.data(), "FSBLOBVERIFY_V1_", 16);
+    buf[16 + 14] = (uint8_t)(kzg::N >> 8); buf[16 + 15] = (uint8_t)kzg::N;          // 16-byte big-endian FIELD_ELEMENTS_PER_BLOB
+    memcpy(buf.data() + 32, blob, (size_t)kzg::N * 32);
+    memcpy(buf.data() + 32 + (size_t)kzg::N * 32, commitment, 48);
+    uint8_t hsh[32], y[32];
+    kzg_sha256(buf.data(), buf.size(), hsh);
+    static const u32 R381[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
+    u32 zw[8];
+    for (int i = 0; i < 8; ++i) { const uint8_t* p = hsh + 4 * (7 - i); zw[i] = ((u32)p[0] << 24) | ((u32)p[1] << 16) | ((u32)p[2] << 8) | (u32)p[3]; }
+    while (geq8(zw, R381)) sub8(zw, R381);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(kzg_load_blob(ctx, s, blob));
+    TRY(kzg_quotient(ctx, s, zw, y));
+    return kzg_commit(ctx, s, s->lagrange_brp, s->tab_lagrange, s->c_single, kzg::N, s->d_q, 1, proof);
+}
+
 extern "C" int32_t dvn_kzg_compute_cell_proofs(dvn_ctx* ctx, const dvn_kzg_setup* s, const uint8_t* blob, uint8_t* proofs /* 128 x 48 */) {
     TRY(enter(ctx));
     if (!s || !blob || !proofs) return fail(DVN_ERR_INVALID_ARG, "NULL argument");

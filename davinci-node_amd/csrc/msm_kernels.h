@@ -508,6 +508,9 @@ static __global__ __launch_bounds__(1024) void k_s2_scatter(const u32* __restric
 // (one wave per SIMD); asking for two waves costs a few spilled values and doubles the occupancy
 template <class Cv> struct AccMinBlocks { static constexpr int value = 1; };
 template <> struct AccMinBlocks<Curve<Fe2P<Fp377Cfg>>> { static constexpr int value = 2; };
+#ifdef DVN_ACC_G1_BLOCKS
+template <> struct AccMinBlocks<Curve<Fe<FpCfg>>> { static constexpr int value = DVN_ACC_G1_BLOCKS; };
+#endif
 template <> struct AccMinBlocks<Curve<Fe2P<Fp381Cfg>>> { static constexpr int value = 2; };
 template <class Cv>
 __global__ __launch_bounds__(128, AccMinBlocks<Cv>::value) void k_accumulate(const u32* __restrict__ points, size_t pts_off,

@@ -325,6 +325,11 @@ int32_t dvn_kzg_setup_free(dvn_ctx* ctx, dvn_kzg_setup* setup);
 int32_t dvn_kzg_blob_to_commitment(dvn_ctx* ctx, const dvn_kzg_setup* setup, const uint8_t* blob /* 131072 */, uint8_t out[48]);
 int32_t dvn_kzg_compute_proof(dvn_ctx* ctx, const dvn_kzg_setup* setup, const uint8_t* blob, const uint8_t z[32],
                               uint8_t proof[48], uint8_t y[32]);
+/* Blob.ComputeBlobProof (/root/reference/types/blobs.go:108-117): opening proof at the Fiat-Shamir point of EIP-4844's
+ * compute_blob_kzg_proof; commitment is NOT checked against the blob (as in the reference). */
+int32_t dvn_kzg_compute_blob_proof(dvn_ctx* ctx, const dvn_kzg_setup* setup, const uint8_t* blob, const uint8_t commitment[48],
+                                   uint8_t proof[48]);
+int32_t dvn_sha256(const uint8_t* data, size_t len, uint8_t out[32]);        /* host only */
 int32_t dvn_kzg_compute_cell_proofs(dvn_ctx* ctx, const dvn_kzg_setup* setup, const uint8_t* blob, uint8_t* proofs /* 128 x 48 */);
 int32_t dvn_kzg_evaluate_barycentric(dvn_ctx* ctx, const dvn_kzg_setup* setup, const uint8_t* blob, const uint8_t z[32], uint8_t y[32]);
 

@@ -5,6 +5,7 @@ reference performs before every state-transition proof:
   Blob.ComputeProof(z)            /root/reference/types/blobs.go:120-133    (gethkzg.ComputeProof -> proof, claim y)
   Blob.ComputeCellProofs          /root/reference/types/blobs.go:97-104     (gethkzg.ComputeCellProofs, 128 proofs)
   EvaluateBarycentricNative       /root/reference/crypto/blobs/barycentric.go:24-170  (IN TREE: restated line by line)
+  Blob.ComputeBlobProof           /root/reference/types/blobs.go:108-117    (gethkzg.ComputeBlobProof, Fiat-Shamir point)
 
 The three geth calls live in un-vendored modules (go-ethereum crypto/kzg4844 -> crate-crypto/go-eth-kzg; go.mod); what
 is restated for them is the published consensus-spec algorithm (EIP-4844 polynomial-commitments.md: blob_to_kzg_commitment,
@@ -296,3 +297,15 @@ def cell_evaluations(coeffs, k: int):
             acc = (acc * x + cf) % R
         out.append(acc)
     return out
+
+
+def compute_challenge(blob: bytes, commitment: bytes) -> int:
+    """EIP-4844 compute_challenge: sha256("FSBLOBVERIFY_V1_" || uint128_be(4096) || blob || commitment) mod r."""
+    import hashlib
+    data = b"FSBLOBVERIFY_V1_" + N.to_bytes(16, "big") + blob + commitment
+    return int.from_bytes(hashlib.sha256(data).digest(), "big") % R
+
+
+def compute_blob_proof(ts: TrustedSetup, blob: bytes, commitment: bytes) -> bytes:
+    """Blob.ComputeBlobProof (types/blobs.go:108-117, gethkzg.ComputeBlobProof): EIP-4844 compute_blob_kzg_proof."""
+    return compute_proof(ts, blob, compute_challenge(blob, commitment))[0]

@@ -221,3 +221,25 @@ def test_gpu_kzg_errors(dev, ctx, pkg, K):
     with pytest.raises(pkg.DvnError):
         no_mono.compute_cell_proofs(bytes(131072))
     no_mono.close()
+
+
+def test_sha256_matches_hashlib(pkg):
+    import ctypes as C
+    import hashlib
+    L = pkg.load_library()
+    for n in (0, 1, 55, 56, 63, 64, 65, 119, 120, 1000, 131072 + 80):
+        m = bytes((5 * i + n) & 0xFF for i in range(n))
+        out = C.create_string_buffer(32)
+        assert L.dvn_sha256(m, n, out) == 0 and out.raw == hashlib.sha256(m).digest()
+
+
+@pytest.mark.gpu
+def test_gpu_blob_proof(dev, ts, K, blobs):
+    """Blob.ComputeBlobProof / ComputeCommitmentAndProof (types/blobs.go:108-148)."""
+    for blob in (blobs[0], small_blob(K, 7)):
+        c, p = dev.compute_commitment_and_proof(blob)
+        assert c == K.blob_to_commitment(ts, blob) and p == K.compute_blob_proof(ts, blob, c)
+    other = K.g1_compress(K.G1_GEN)                        # not the blob's commitment: still the opening at the derived point
+    assert dev.compute_blob_proof(blobs[1], other) == K.compute_blob_proof(ts, blobs[1], other)
+    c, cells = dev.compute_commitment_and_cell_proofs(blobs[1])
+    assert c == K.blob_to_commitment(ts, blobs[1]) and len(cells) == 128
