@@ -243,3 +243,40 @@ def test_gpu_blob_proof(dev, ts, K, blobs):
     assert dev.compute_blob_proof(blobs[1], other) == K.compute_blob_proof(ts, blobs[1], other)
     c, cells = dev.compute_commitment_and_cell_proofs(blobs[1])
     assert c == K.blob_to_commitment(ts, blobs[1]) and len(cells) == 128
+
+
+@pytest.mark.gpu
+def test_gpu_kzg_concurrent_callers(dev, ctx, pkg, K, ts, blobs, orc):
+    """cgo calls arrive on arbitrary OS threads: blob operations, BN254 MSMs and a second setup on the same
+    context interleave from four threads; every result must still be bit-exact."""
+    import threading
+    want_c = [dev.compute_commitment(b) for b in blobs]
+    want_p = [dev.compute_proof(b, 777 + i) for i, b in enumerate(blobs)]
+    want_cells = dev.compute_cell_proofs(blobs[0])
+    n = 1 << 12
+    pts_host = orc.g1_synthetic_points(0xDA71C1, n); scal = orc.scalars(1, 0, n)
+    pts = ctx.upload_g1(pts_host)
+    want_msm = orc.msm_g1(pts_host, scal)
+    errs = []
+
+    def worker(tid):
+        try:
+            for it in range(4):
+                k = (tid + it) % 2
+                if tid == 0:
+                    assert dev.compute_cell_proofs(blobs[0]) == want_cells
+                elif tid == 1:
+                    assert (orc.g1_jac_to_affine(ctx.msm_g1(pts, scal)) == want_msm).all()
+                else:
+                    assert dev.compute_commitment(blobs[k]) == want_c[k]
+                    assert dev.compute_proof(blobs[k], 777 + k) == want_p[k]
+        except Exception as e:                                  # noqa: BLE001
+            errs.append((tid, repr(e)))
+
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    pts.free()
+    assert not errs, errs
