@@ -118,6 +118,7 @@ def load_library():
         "dvn_bls12381_r1cs_synthetic": (i32, [u64, u32, u32, C.POINTER(vp)]),
         "dvn_bls12381_groth16_setup": (i32, [vp, vp, u64, C.POINTER(vp)]),
         "dvn_bls12381_groth16_prove": (i32, [vp, vp, vp, u32, vp, vp, vp]),
+        "dvn_groth16_vk_export": (i32, [vp, vp, sz, C.POINTER(sz)]),
         "dvn_r1cs_synthetic_committed": (i32, [u64, u32, u32, u32, C.POINTER(vp)]),
         "dvn_groth16_prove_committed": (i32, [vp, vp, vp, u32, vp, vp, vp, vp, vp, vp]),
         "dvn_keccak256": (i32, [vp, sz, vp]),
@@ -172,7 +173,7 @@ EXPORTED_SYMBOLS = [
     "dvn_bls12381_points_upload_g1", "dvn_bls12381_points_upload_g2", "dvn_bls12381_points_synthetic_g1", "dvn_bls12381_points_download",
     "dvn_bls12381_scalars_synthetic", "dvn_bls12381_msm_g1", "dvn_bls12381_msm_g2", "dvn_bls12381_ntt_domain", "dvn_bls12381_ntt", "dvn_bls12381_groth16_compute_h",
     "dvn_bls12381_r1cs_synthetic", "dvn_bls12381_groth16_setup", "dvn_bls12381_groth16_prove", "dvn_r1cs_curve",
-    "dvn_r1cs_synthetic_committed", "dvn_groth16_prove_committed", "dvn_keccak256",
+    "dvn_r1cs_synthetic_committed", "dvn_groth16_prove_committed", "dvn_keccak256", "dvn_groth16_vk_export",
     "dvn_kzg_setup_load", "dvn_kzg_setup_free", "dvn_kzg_blob_to_commitment", "dvn_kzg_compute_proof", "dvn_kzg_compute_cell_proofs",
     "dvn_kzg_evaluate_barycentric", "dvn_kzg_compute_blob_proof", "dvn_sha256",
     "dvn_bw6761_points_upload", "dvn_bw6761_points_synthetic", "dvn_bw6761_points_download", "dvn_bw6761_scalars_synthetic", "dvn_bw6761_msm",
@@ -463,6 +464,20 @@ class Groth16Key:
             witness = np.ascontiguousarray(witness, dtype=np.uint64); wp, fl = _host(witness), 0
         self.ctx._chk(getattr(self.ctx.L, self._prefix + "groth16_prove")(self.ctx.h, self.h, wp, fl, _host(r_mont), _host(s_mont), _host(out)))
         return {"Ar": out[0:a1].copy(), "Bs": out[a1:a1 + a2].copy(), "Krs": out[a1 + a2:2 * a1 + a2].copy()}
+
+    def verifying_key(self, n_public: int, committed: bool = False) -> dict:
+        """The vk half of Setup: {'alpha': (a1,), 'beta'/'gamma'/'delta': (a2,), 'ic': (n_public, a1)[, 'pedersen_g', 'pedersen_gsigmaneg']}."""
+        n = C.c_size_t()
+        self.ctx._chk(self.ctx.L.dvn_groth16_vk_export(self.h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint64)
+        self.ctx._chk(self.ctx.L.dvn_groth16_vk_export(self.h, _host(out), n.value, C.byref(n)))
+        a1, a2 = self._a1, self._a2
+        vk = {"alpha": out[0:a1], "beta": out[a1:a1 + a2], "gamma": out[a1 + a2:a1 + 2 * a2], "delta": out[a1 + 2 * a2:a1 + 3 * a2]}
+        at = a1 + 3 * a2
+        vk["ic"] = out[at:at + n_public * a1].reshape(n_public, a1); at += n_public * a1
+        if committed:
+            vk["pedersen_g"] = out[at:at + a2]; vk["pedersen_gsigmaneg"] = out[at + a2:at + 2 * a2]
+        return vk
 
     def prove_committed(self, witness, r_mont: np.ndarray, s_mont: np.ndarray) -> dict:
         """Proof with one BSB22 commitment (BN254): adds 'Commitment', 'CommitmentPok' (8 uint64 each) and 'challenge' (4)."""

@@ -85,6 +85,18 @@ extern "C" int32_t dvn_groth16_pk_info(const dvn_groth16_pk* pk, uint32_t* log_n
     return DVN_OK;
 }
 
+// The verifying key Setup produced next to the proving key (groth16.Setup returns both, /root/reference/prover/setup.go:15-28),
+// as gnark affine Montgomery images: alpha (G1) | beta | gamma | delta (G2) | IC[n_public] (G1) | with a commitment: Pedersen
+// G | GSigmaNeg (G2).  n_words receives the total; out may be NULL to query it.
+extern "C" int32_t dvn_groth16_vk_export(const dvn_groth16_pk* pk, uint64_t* out, size_t cap_words, size_t* n_words) {
+    if (!pk || !n_words) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    *n_words = pk->vk_words.size();
+    if (!out) return DVN_OK;
+    if (cap_words < pk->vk_words.size()) return fail(DVN_ERR_INVALID_ARG, "buffer holds %zu words, the key needs %zu", cap_words, pk->vk_words.size());
+    memcpy(out, pk->vk_words.data(), pk->vk_words.size() * 8);
+    return DVN_OK;
+}
+
 extern "C" int32_t dvn_groth16_last_ms(const dvn_groth16_pk* pk, float* ms_h, float* ms_msm, float* ms_total) {
     if (!pk) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (ms_h) *ms_h = pk->ms_h;

@@ -64,6 +64,9 @@ struct dvn_groth16_pk {
     u32 commit_wire = 0, n_committed = 0, tail = 0;
     std::vector<u32> public_committed;
     dvn_points *Basis = nullptr, *BasisSigma = nullptr;
+    // verifying key as gnark affine Montgomery images (uint64 words): alpha (G1) | beta | gamma | delta (G2) | IC[n_public] (G1:
+    // CONSTANT, PUB_i of the Solidity verifier) | Pedersen G | Pedersen GSigmaNeg (G2; only with a commitment)
+    std::vector<uint64_t> vk_words;
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -432,6 +435,40 @@ template <class SU> static int32_t groth16_setup(dvn_ctx* ctx, const dvn_r1cs* c
         hk->beta2 = H2::normalize(host_mul<H2, S>(hg2, kw));
         fr_canonical_words<S>(delta, kw); hk->delta = H1::normalize(host_mul<H1, S>(hg1, kw));
         hk->delta2 = H2::normalize(host_mul<H2, S>(hg2, kw));
+        // verifying key (groth16.Setup returns (pk, vk), /root/reference/prover/setup.go:15-28): alpha, beta, gamma, delta and
+        // IC_i = [(beta A_i + alpha B_i + C_i)(tau) / gamma]G1 over the public section; with a commitment the Pedersen pair
+        // G, GSigmaNeg = -sigma G (statetransition_vkey.sol:62-114 holds exactly these constants, beta/gamma/delta negated)
+        {
+            constexpr size_t A1 = G1::AW / 2, A2 = G2::AW / 2;
+            auto put1 = [&](const typename H1::X& pnt) { uint64_t j[3 * A1 / 2 + 1]; H1::write_jac(pnt, j); if (H1::is_inf(pnt)) memset(j, 0, sizeof(j)); pk->vk_words.insert(pk->vk_words.end(), j, j + A1); };
+            auto put2 = [&](const typename H2::X& pnt) { uint64_t j[3 * A2 / 2 + 1]; H2::write_jac(pnt, j); if (H2::is_inf(pnt)) memset(j, 0, sizeof(j)); pk->vk_words.insert(pk->vk_words.end(), j, j + A2); };
+            put1(hk->alpha); put2(hk->beta2);
+            fr_canonical_words<S>(tw[3], kw); put2(host_mul<H2, S>(hg2, kw));
+            put2(hk->delta2);
+            const Fe<S> ginv = fe_inv<S>(tw[3]);
+            u32 hv[3 * EW];
+            fr_pack_internal<S>(alpha, hv); fr_pack_internal<S>(beta, hv + EW); fr_pack_internal<S>(ginv, hv + 2 * EW);
+            u32* d_v = nullptr;
+            HIP_TRY(hipMalloc((void**)&d_v, sizeof(hv) + (size_t)cs->n_public * EB));
+            hipError_t e = hipMemcpy(d_v, hv, sizeof(hv), hipMemcpyHostToDevice);
+            dvn_points* ic = nullptr;
+            int32_t rc3 = e == hipSuccess ? DVN_OK : fail(DVN_ERR_DEVICE, "vk upload failed: %s", hipGetErrorString(e));
+            if (rc3 == DVN_OK) {
+                k_key_k<S><<<(cs->n_public + 63) / 64, 64, 0, st>>>(d_t[0], d_t[1], d_t[2], d_v, d_v + 3 * EW, 0, cs->n_public);
+                rc3 = fixed_base_points<G1, S>(ctx, g1, d_v + 3 * EW, cs->n_public, 1, &ic);
+            }
+            (void)hipFree(d_v);
+            TRY(rc3);
+            const size_t at = pk->vk_words.size();
+            pk->vk_words.resize(at + (size_t)cs->n_public * A1);
+            rc3 = points_download<G1>(ctx, ic, 0, cs->n_public, pk->vk_words.data() + at);
+            (void)hipFree(ic->d); delete ic;
+            TRY(rc3);
+            if (cs->n_committed) {
+                put2(hg2);
+                fr_canonical_words<S>(fe_neg<S>(tw[5]), kw); put2(host_mul<H2, S>(hg2, kw));
+            }
+        }
         return DVN_OK;
     };
     rc = body();

@@ -301,6 +301,10 @@ int32_t dvn_bw6761_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_
  * keccak256(C.x || C.y || publicCommitted) mod r that the reference's Solidity verifier recomputes
  * (statetransition_vkey.sol:659-676), the completion of the witness, then the proof as dvn_groth16_prove.
  * Together with dvn_groth16_proof_abi_encode this yields the calldata of solidity/solidity.go:85-116. */
+/* The verifying key of a Setup (the reference's Setup returns (pk, vk), /root/reference/prover/setup.go:15-28) as affine
+ * Montgomery images of the key's curve: alpha (G1) | beta, gamma, delta (G2) | IC[n_public] (G1: CONSTANT and PUB_i of the
+ * generated Solidity verifier) | with a commitment: Pedersen G, GSigmaNeg (G2).  out = NULL queries the size. */
+int32_t dvn_groth16_vk_export(const dvn_groth16_pk* pk, uint64_t* out, size_t cap_words, size_t* n_words);
 int32_t dvn_r1cs_synthetic_committed(uint64_t seed, uint32_t n_constraints, uint32_t n_public, uint32_t n_committed, dvn_r1cs** out);
 int32_t dvn_groth16_prove_committed(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
                                     const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32],

@@ -684,7 +684,13 @@ def groth16_committed_expected(cs: SyntheticR1CSCommitted, seed: int, r: int, s:
     priv = sum(w[i] * t[i] for i in range(first_k, m)) % R * dinv % R
     krs = (priv + h_tau * z_tau % R * dinv + s * ar + r * bs - r * s % R * delta) % R
     vkx = (sum(w[i] * t[i] for i in range(cs.n_public)) % R * ginv + cexp) % R     # CONSTANT + inputs + challenge wire, + C
+    # the verifying key in the shape of the constants of config/statetransition_vkey.sol:62-114
+    vk = {"ALPHA": g1_mul(G1_GEN, alpha), "BETA_NEG": g2_neg(g2_mul(G2_GEN, beta)), "GAMMA_NEG": g2_neg(g2_mul(G2_GEN, gamma)),
+          "DELTA_NEG": g2_neg(g2_mul(G2_GEN, delta)), "CONSTANT": g1_mul(G1_GEN, t[0] * ginv % R),
+          "PUB": [g1_mul(G1_GEN, t[i] * ginv % R) for i in range(1, cs.n_public)],
+          "PEDERSEN_G": G2_GEN, "PEDERSEN_GSIGMANEG": g2_neg(g2_mul(G2_GEN, sigma)),
+          "PUBLIC_COMMITTED": [i - 1 for i in cs.public_committed]}
     return {"Ar": g1_mul(G1_GEN, ar), "Bs": g2_mul(G2_GEN, bs), "Krs": g1_mul(G1_GEN, krs), "Commitment": cpt,
-            "CommitmentPok": g1_mul(G1_GEN, sigma * cexp % R), "challenge": ch, "witness": w,
+            "CommitmentPok": g1_mul(G1_GEN, sigma * cexp % R), "challenge": ch, "witness": w, "vk": vk,
             "exponents": {"ar": ar, "bs": bs, "krs": krs, "vkx": vkx, "alpha": alpha, "beta": beta, "gamma": gamma, "delta": delta,
                           "sigma": sigma, "cexp": cexp}}
