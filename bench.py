@@ -320,6 +320,28 @@ def main():
                            "key_sizes": key.sizes, "witness": "resident in HBM; solve = sparse (A w, B w, C w) on device"}
             ctx.free(dw); key.free(); cs.free()
 
+        # CPU comparator for the proof metric (rank 0, bounded: one proof's worth of primitives): the oracle's own C Pippenger /
+        # NTT (NOT gnark) on the same sizes as the BN254 key above -- four G1 MSMs, one G2 MSM, computeH at n = 2^20 -- on the
+        # threads this box allows.  Points are synthetic (MSM cost does not depend on which points).
+        if not args.no_cpu_baseline and "groth16_synthetic_2^20" in extras:
+            from oracle import cpu as orc
+            ks = extras["groth16_synthetic_2^20"]["key_sizes"]
+            cores = orc.usable_cores()
+            hp1 = orc.g1_synthetic_points(0xDA71C1, 1 << 20, cores); hs = orc.scalars(1, 0, 1 << 20)
+            hp2 = orc.g2_synthetic_points(0xDA71C1, min(ks["B2"], 1 << 19), cores)
+            t0 = time.perf_counter()
+            for nm in ("A", "B", "K", "Z"):
+                m = min(ks[nm], 1 << 20)
+                orc.msm_g1(hp1[:m], hs[:m], cores)
+            t1 = time.perf_counter()
+            orc.msm_g2(hp2, hs[:hp2.shape[0]], cores)
+            t2 = time.perf_counter()
+            orc.compute_h(hs, hs, hs, 20, cores)
+            t3 = time.perf_counter()
+            extras["groth16_cpu_port_2^20"] = {"s_per_proof": round(t3 - t0, 3), "proofs_per_s": round(1 / (t3 - t0), 4), "cores": cores,
+                                               "s_msm_g1_x4": round(t1 - t0, 3), "s_msm_g2": round(t2 - t1, 3), "s_compute_h": round(t3 - t2, 3),
+                                               "kind": "port (oracle/bn254_cpu.c: own C Pippenger + NTT, not gnark); solver and blinding excluded"}
+            del hp1, hp2, hs
         # the statetransition shape proper: 8 public inputs + ONE BSB22 commitment (statetransition_vkey.sol:97-114) -- the proof
         # additionally carries Commitments[0] / CommitmentPok and the keccak challenge round trip sits inside the timed region
         cs = pkg.R1CS(7, 1 << 20, 9, n_committed=1 << 14)
