@@ -64,6 +64,7 @@ def load_library():
         "dvn_points_free": (i32, [vp, vp]),
         "dvn_msm_g1": (i32, [vp, vp, sz, sz, vp, u32, vp]),
         "dvn_msm_g2": (i32, [vp, vp, sz, sz, vp, u32, vp]),
+        "dvn_msm_g1_batched": (i32, [vp, vp, sz, sz, vp, u32, u32, vp]),
         "dvn_msm_g1_submit": (i32, [vp, vp, sz, sz, vp, u32, C.POINTER(i32)]),
         "dvn_msm_g1_collect": (i32, [vp, i32, vp]),
         "dvn_msm_g2_submit": (i32, [vp, vp, sz, sz, vp, u32, C.POINTER(i32)]),
@@ -162,7 +163,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "dvn_init", "dvn_shutdown", "dvn_last_error", "dvn_version", "dvn_malloc", "dvn_free", "dvn_memcpy_h2d",
     "dvn_memcpy_d2h", "dvn_synchronize", "dvn_points_upload_g1", "dvn_points_upload_g2", "dvn_points_synthetic_g1",
-    "dvn_points_synthetic_g2", "dvn_scalars_synthetic", "dvn_points_set_expanded", "dvn_points_download", "dvn_points_len", "dvn_points_free", "dvn_msm_g1", "dvn_msm_g2",
+    "dvn_points_synthetic_g2", "dvn_scalars_synthetic", "dvn_points_set_expanded", "dvn_points_download", "dvn_points_len", "dvn_points_free", "dvn_msm_g1", "dvn_msm_g2", "dvn_msm_g1_batched",
     "dvn_msm_g1_submit", "dvn_msm_g1_collect", "dvn_msm_g2_submit", "dvn_msm_g2_collect", "dvn_msm_plan", "dvn_msm_plan_points", "dvn_msm_g1_windows", "dvn_msm_g1_windows_submit", "dvn_msm_g1_windows_collect", "dvn_msm_combine_g1", "dvn_ntt_domain", "dvn_ntt_domain_free", "dvn_ntt",
     "dvn_groth16_compute_h", "dvn_last_kernel_ms", "dvn_r1cs_synthetic", "dvn_r1cs_info", "dvn_r1cs_witness", "dvn_r1cs_free",
     "dvn_groth16_setup", "dvn_groth16_pk_info", "dvn_groth16_pk_free", "dvn_groth16_prove", "dvn_groth16_last_ms", "dvn_groth16_prove_shard", "dvn_groth16_prove_combine",
@@ -305,6 +306,15 @@ class Context:
         sp, ns, fl = self._scalars(scalars, n)
         out = np.zeros(12, dtype=np.uint64)
         self._chk(self.L.dvn_msm_g1(self.h, pts.handle, off, ns, sp, fl, _host(out)))
+        return out
+
+    def msm_g1_batched(self, pts: Points, scalars: np.ndarray, off: int = 0) -> np.ndarray:
+        """scalars: (batch, n, 4) uint64 host array -> (batch, 12) G1Jac images, one pass over the shared point set."""
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+        assert scalars.ndim == 3 and scalars.shape[2] == 4
+        batch, n = scalars.shape[0], scalars.shape[1]
+        out = np.zeros((batch, 12), dtype=np.uint64)
+        self._chk(self.L.dvn_msm_g1_batched(self.h, pts.handle, off, n, _host(scalars), batch, 0, _host(out)))
         return out
 
     def msm_g1_submit(self, pts: Points, scalars, off: int = 0, n: int | None = None) -> int:

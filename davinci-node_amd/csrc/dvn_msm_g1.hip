@@ -15,6 +15,49 @@ extern "C" int32_t dvn_msm_g1(dvn_ctx* ctx, const dvn_points* pts, size_t off, s
     return msm_full<G1>(ctx, pts, 1, off, n, scalars, flags, out_jac);
 }
 
+// B MultiExps over ONE point set in one pass of the pipeline: every (vector, window) pair is a virtual window of the same
+// sorted entry list (msm_driver.h msm_windows_staged, batched mode), the window sums are combined per vector on the device.
+// For many commitments over one basis (a PLONK prover's wire / quotient polynomials over one SRS, several BSB22 commitments
+// over one key): B small MSMs cost one launch sequence instead of B.  scalars: batch x n images, vector b at [b*n, (b+1)*n).
+extern "C" int32_t dvn_msm_g1_batched(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t batch,
+                                      uint32_t flags, uint64_t* out_jac /* batch x 12 */) {
+    TRY(enter(ctx));
+    if (!pts || !out_jac || (!scalars && n && batch)) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    if (pts->curve != 1 || pts->suite != 0) return fail(DVN_ERR_INVALID_ARG, "point set is not BN254 G1");
+    if (off > pts->n || n > pts->n - off) return fail(DVN_ERR_INVALID_ARG, "len(points) != len(scalars): range [%zu, %zu) outside point set of %zu", off, off + n, pts->n);
+    typedef dvn_host::HG1 HG;
+    auto write_inf = [&](uint32_t b) { HG::write_jac(HG::infinity(), out_jac + (size_t)b * 12); };
+    if (batch == 0) return DVN_OK;
+    if (n == 0) { for (uint32_t b = 0; b < batch; ++b) write_inf(b); return DVN_OK; }
+    u32 c, nwin;
+    msm_plan(n, &c, &nwin);
+    if ((size_t)batch * nwin * n >= ((size_t)1 << 31)) return fail(DVN_ERR_INVALID_ARG, "batched MSM too large: batch * windows * n must stay below 2^31");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    u32 *d_s = nullptr, *d_out = nullptr;
+    const size_t sbytes = (size_t)batch * n * 32;
+    auto cleanup = [&]() { if (d_s) (void)hipFree(d_s); if (d_out) (void)hipFree(d_out); };
+    HIP_TRY(hipMalloc((void**)&d_out, (size_t)batch * G1::XW * 4));
+    const u32* d_scalars = (const u32*)scalars;
+    if (!(flags & DVN_MSM_SCALARS_ON_DEVICE)) {
+        hipError_t e = hipMalloc((void**)&d_s, sbytes);
+        if (e == hipSuccess) e = hipMemcpy(d_s, scalars, sbytes, hipMemcpyHostToDevice);        // caller's buffer is free on return
+        if (e != hipSuccess) { cleanup(); (void)hipGetLastError(); return fail(DVN_ERR_OOM, "scalar upload failed: %s", hipGetErrorString(e)); }
+        d_scalars = d_s;
+    }
+    MsmLane* L = nullptr;
+    int32_t rc = msm_batched_submit<G1>(ctx, pts, off, n, d_scalars, batch, c, d_out, &L);
+    std::vector<u32> h((size_t)batch * G1::XW);
+    if (rc == DVN_OK) {
+        hipError_t e = hipMemcpyAsync(h.data(), d_out, h.size() * 4, hipMemcpyDeviceToHost, L->stream);
+        rc = lane_wait(ctx, *L);
+        if (rc == DVN_OK && e != hipSuccess) { (void)hipGetLastError(); rc = fail(DVN_ERR_DEVICE, "result copy failed: %s", hipGetErrorString(e)); }
+    }
+    cleanup();
+    TRY(rc);
+    for (uint32_t b = 0; b < batch; ++b) HG::write_jac(HG::load_device(h.data() + (size_t)b * G1::XW), out_jac + (size_t)b * 12);
+    return DVN_OK;
+}
+
 // (window_bits, nwin, combine_bits) the library will use for an n-scalar MSM over this point set.  Expanded sets
 //  have pts-specific windows and combine_bits = 0: partial results of window ranges simply add up.
 extern "C" int32_t dvn_msm_plan_points(const dvn_points* pts, size_t n, uint32_t* window_bits, uint32_t* nwin, uint32_t* combine_bits) {

@@ -86,6 +86,11 @@ int32_t dvn_msm_g1(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, co
                    uint32_t flags, uint64_t out_jac[12]);
 int32_t dvn_msm_g2(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars_mont,
                    uint32_t flags, uint64_t out_jac[24]);
+/* `batch` MultiExps over ONE point set in one pass (many commitments over one basis): scalars_mont = batch x n x 4 uint64,
+ * vector b at [b*n, (b+1)*n) (host, or device with DVN_MSM_SCALARS_ON_DEVICE); out_jac = batch x 12, each as dvn_msm_g1's.
+ * batch * windows(n) * n must stay below 2^31. */
+int32_t dvn_msm_g1_batched(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars_mont,
+                           uint32_t batch, uint32_t flags, uint64_t* out_jac);
 /* Asynchronous pair: _submit queues the MSM on one of the context's four lanes (own stream + workspace) and returns a
  * ticket; _collect waits for it and writes the result.  With several MSMs in flight the sort and the latency-bound tail of
  * one run under the accumulate kernel of the other (measured +10 % throughput at 2^22, +19 % at 2^20, +52 % at 2^18).

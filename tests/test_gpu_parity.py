@@ -376,3 +376,33 @@ def test_compute_h_rejects_oversized_input(ctx, orc, pkg):
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,batch", [(3000, 5), (1, 3), (70000, 2), (257, 16)])
+def test_msm_g1_batched_equals_individual_msms(ctx, orc, n, batch):
+    """dvn_msm_g1_batched: B scalar vectors over one point set in one pass == B separate MultiExps (oracle), incl. an all-zero
+    vector, a vector of ones (one hot bucket per window) and r - 1 scalars."""
+    pts_host = orc.g1_synthetic_points(0xBA7C4, n)
+    pts = ctx.upload_g1(pts_host)
+    vecs = [orc.scalars(50 + b, b % 2, n) for b in range(batch)]
+    vecs[0] = np.zeros((n, 4), dtype=np.uint64)
+    one = orc.fr_to_mont(np.array([1, 0, 0, 0], dtype=np.uint64))
+    if batch > 2:
+        vecs[2] = np.tile(one, (n, 1))
+    rm1 = np.array([0x43E1F593F0000000, 0x2833E84879B97091, 0xB85045B68181585D, 0x30644E72E131A029], dtype=np.uint64)   # r - 1
+    vecs[1][0] = orc.fr_to_mont(rm1)
+    got = ctx.msm_g1_batched(pts, np.stack(vecs))
+    for b in range(batch):
+        assert (orc.g1_jac_to_affine(got[b]) == orc.msm_g1(pts_host, vecs[b])).all(), b
+    assert (got[0][8:12] == 0).all()                      # infinity: Z = 0
+    pts.free()
+
+
+@pytest.mark.gpu
+def test_msm_g1_batched_argument_errors(ctx, pkg, orc):
+    pts = ctx.upload_g1(orc.g1_synthetic_points(1, 64))
+    with pytest.raises(pkg.DvnError):
+        ctx.msm_g1_batched(pts, np.zeros((2, 65, 4), dtype=np.uint64))       # len(points) != len(scalars)
+    assert ctx.msm_g1_batched(pts, np.zeros((0, 64, 4), dtype=np.uint64)).shape == (0, 12)
+    pts.free()
