@@ -320,6 +320,22 @@ def main():
                            "key_sizes": key.sizes, "witness": "resident in HBM; solve = sparse (A w, B w, C w) on device"}
             ctx.free(dw); key.free(); cs.free()
 
+        # the same shape at n = 2^22 constraints (SURVEY.md §8d config 5's nominal size), BN254
+        cs = pkg.R1CS(7, 1 << 22, 9)
+        key = pkg.Groth16Key(ctx, cs, 3)
+        dw = ctx.to_device(cs.witness())
+        rs = np.zeros((2, 4), dtype=np.uint64); rs[0, 0], rs[1, 0] = 5, 7
+        p22 = key.prove(dw, rs[0], rs[1])
+        t0 = time.perf_counter()
+        for _ in range(3):
+            key.prove(dw, rs[0], rs[1])
+        dtp = (time.perf_counter() - t0) / 3
+        extras["groth16_synthetic_2^22"] = {"proofs_per_s": round(1 / dtp, 3), "ms_per_proof": round(dtp * 1e3, 3), "key_sizes": key.sizes}
+        if not args.no_cpu_baseline:                     # checker leg: the trapdoor identity at this size (oracle, O(n) field work)
+            from oracle import cpu as orc
+            _, want22 = orc.groth16_synthetic_expected(7, 1 << 22, 9, 3, rs[0], rs[1])
+            extras["groth16_synthetic_2^22"]["trapdoor_identity"] = bool(all((p22[k] == want22[k]).all() for k in want22))
+        ctx.free(dw); key.free(); cs.free()
         # CPU comparator for the proof metric (rank 0, bounded: one proof's worth of primitives): the oracle's own C Pippenger /
         # NTT (NOT gnark) on the same sizes as the BN254 key above -- four G1 MSMs, one G2 MSM, computeH at n = 2^20 -- on the
         # threads this box allows.  Points are synthetic (MSM cost does not depend on which points).
