@@ -318,7 +318,7 @@ class Context:
         return out
 
     def msm_g1_submit(self, pts: Points, scalars, off: int = 0, n: int | None = None) -> int:
-        """Queue a G1 MSM on a free lane; returns the ticket for msm_g1_collect (at most two outstanding)."""
+        """Queue a G1 MSM on a free lane; returns the ticket for msm_g1_collect (at most four outstanding: one per lane)."""
         sp, ns, fl = self._scalars(scalars, n)
         t = C.c_int32()
         self._chk(self.L.dvn_msm_g1_submit(self.h, pts.handle, off, ns, sp, fl, C.byref(t)))

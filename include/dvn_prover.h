@@ -94,8 +94,8 @@ int32_t dvn_msm_g1_batched(dvn_ctx* ctx, const dvn_points* pts, size_t off, size
 /* Asynchronous pair: _submit queues the MSM on one of the context's four lanes (own stream + workspace) and returns a
  * ticket; _collect waits for it and writes the result.  With several MSMs in flight the sort and the latency-bound tail of
  * one run under the accumulate kernel of the other (measured +10 % throughput at 2^22, +19 % at 2^20, +52 % at 2^18).
- * Host scalars are copied before _submit returns; DEVICE scalars must stay untouched until _collect.  At most two
- * tickets may be outstanding per context. */
+ * Host scalars are copied before _submit returns; DEVICE scalars must stay untouched until _collect.  At most four
+ * tickets may be outstanding per context (one per lane). */
 int32_t dvn_msm_g1_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars_mont,
                           uint32_t flags, int32_t* ticket);
 int32_t dvn_msm_g1_collect(dvn_ctx* ctx, int32_t ticket, uint64_t out_jac[12]);
