@@ -120,6 +120,9 @@ def load_library():
         "dvn_bls12381_groth16_setup": (i32, [vp, vp, u64, C.POINTER(vp)]),
         "dvn_bls12381_groth16_prove": (i32, [vp, vp, vp, u32, vp, vp, vp]),
         "dvn_groth16_vk_export": (i32, [vp, vp, sz, C.POINTER(sz)]),
+        "dvn_groth16_pk_import": (i32, [vp, vp, C.POINTER(vp)]),
+        "dvn_groth16_prove_solved": (i32, [vp, vp, vp, vp, vp, vp, sz, vp, vp, vp]),
+        "dvn_groth16_pk_export_arrays": (i32, [vp, vp, C.c_int, vp, sz, C.POINTER(sz)]),
         "dvn_r1cs_synthetic_committed": (i32, [u64, u32, u32, u32, C.POINTER(vp)]),
         "dvn_groth16_prove_committed": (i32, [vp, vp, vp, u32, vp, vp, vp, vp, vp, vp]),
         "dvn_keccak256": (i32, [vp, sz, vp]),
@@ -174,7 +177,7 @@ EXPORTED_SYMBOLS = [
     "dvn_bls12381_points_upload_g1", "dvn_bls12381_points_upload_g2", "dvn_bls12381_points_synthetic_g1", "dvn_bls12381_points_download",
     "dvn_bls12381_scalars_synthetic", "dvn_bls12381_msm_g1", "dvn_bls12381_msm_g2", "dvn_bls12381_ntt_domain", "dvn_bls12381_ntt", "dvn_bls12381_groth16_compute_h",
     "dvn_bls12381_r1cs_synthetic", "dvn_bls12381_groth16_setup", "dvn_bls12381_groth16_prove", "dvn_r1cs_curve",
-    "dvn_r1cs_synthetic_committed", "dvn_groth16_prove_committed", "dvn_keccak256", "dvn_groth16_vk_export",
+    "dvn_r1cs_synthetic_committed", "dvn_groth16_prove_committed", "dvn_keccak256", "dvn_groth16_vk_export", "dvn_groth16_pk_import", "dvn_groth16_prove_solved", "dvn_groth16_pk_export_arrays",
     "dvn_kzg_setup_load", "dvn_kzg_setup_free", "dvn_kzg_blob_to_commitment", "dvn_kzg_compute_proof", "dvn_kzg_compute_cell_proofs",
     "dvn_kzg_evaluate_barycentric", "dvn_kzg_compute_blob_proof", "dvn_sha256",
     "dvn_bw6761_points_upload", "dvn_bw6761_points_synthetic", "dvn_bw6761_points_download", "dvn_bw6761_scalars_synthetic", "dvn_bw6761_msm",
@@ -489,6 +492,21 @@ class Groth16Key:
             vk["pedersen_g"] = out[at:at + a2]; vk["pedersen_gsigmaneg"] = out[at + a2:at + 2 * a2]
         return vk
 
+    def export_arrays(self, n_wires: int, n_public: int) -> dict:
+        """The key's arrays in the layout dvn_groth16_pk_import takes (BN254 keys without commitment)."""
+        def get(which, dtype=np.uint64):
+            n = C.c_size_t()
+            self.ctx._chk(self.ctx.L.dvn_groth16_pk_export_arrays(self.ctx.h, self.h, which, None, 0, C.byref(n)))
+            out = np.zeros(max(n.value, 1), dtype=np.uint64)
+            self.ctx._chk(self.ctx.L.dvn_groth16_pk_export_arrays(self.ctx.h, self.h, which, _host(out), out.size, C.byref(n)))
+            return out[:n.value]
+        arr = {"A": get(0).reshape(-1, 8), "B": get(1).reshape(-1, 8), "K": get(2).reshape(-1, 8), "Z": get(3).reshape(-1, 8),
+               "B2": get(4).reshape(-1, 16), "consts": get(7)}
+        arr["idxA"] = get(5).view(np.uint32)[:self.sizes["A"]].copy()
+        arr["idxB"] = get(6).view(np.uint32)[:self.sizes["B"]].copy()
+        arr["idxK"] = np.arange(n_public, n_wires, dtype=np.uint32)
+        return arr
+
     def prove_committed(self, witness, r_mont: np.ndarray, s_mont: np.ndarray) -> dict:
         """Proof with one BSB22 commitment (BN254): adds 'Commitment', 'CommitmentPok' (8 uint64 each) and 'challenge' (4)."""
         assert self.curve == "bn254"
@@ -524,6 +542,48 @@ class Groth16Key:
         a, b, c = C.c_float(), C.c_float(), C.c_float()
         self.ctx.L.dvn_groth16_last_ms(self.h, C.byref(a), C.byref(b), C.byref(c))
         return {"compute_h": a.value, "msm": b.value, "total": c.value}
+
+    def free(self):
+        if self.h:
+            self.ctx._chk(self.ctx.L.dvn_groth16_pk_free(self.ctx.h, self.h))
+            self.h = None
+
+
+class KeyArrays(C.Structure):
+    """dvn_groth16_key_arrays (include/dvn_prover.h)."""
+    _fields_ = [("log_n", C.c_uint32), ("n_wires", C.c_uint64),
+                ("A", C.c_void_p), ("B", C.c_void_p), ("K", C.c_void_p), ("Z", C.c_void_p), ("B2", C.c_void_p),
+                ("nA", C.c_uint64), ("nB", C.c_uint64), ("nK", C.c_uint64), ("nZ", C.c_uint64),
+                ("idxA", C.c_void_p), ("idxB", C.c_void_p), ("idxK", C.c_void_p),
+                ("alpha_g1", C.c_void_p), ("beta_g1", C.c_void_p), ("delta_g1", C.c_void_p), ("beta_g2", C.c_void_p), ("delta_g2", C.c_void_p)]
+
+
+class ImportedKey:
+    """A gnark proving key handed over as arrays (dvn_groth16_pk_import); proofs come from the solver's output
+    (dvn_groth16_prove_solved).  arrays: dict with A, B, K, Z (n,8), B2 (n,16) uint64; idxA, idxB, idxK uint32; consts (56,) uint64."""
+
+    def __init__(self, ctx: "Context", log_n: int, n_wires: int, arrays: dict):
+        self.ctx = ctx
+        keep = {k: np.ascontiguousarray(arrays[k], dtype=np.uint64) for k in ("A", "B", "K", "Z", "B2", "consts")}
+        keep.update({k: np.ascontiguousarray(arrays[k], dtype=np.uint32) for k in ("idxA", "idxB", "idxK")})
+        c = keep["consts"]
+        ptr = lambda a: a.ctypes.data
+        ka = KeyArrays(log_n, n_wires, ptr(keep["A"]), ptr(keep["B"]), ptr(keep["K"]), ptr(keep["Z"]), ptr(keep["B2"]),
+                       keep["A"].shape[0], keep["B"].shape[0], keep["K"].shape[0], keep["Z"].shape[0],
+                       ptr(keep["idxA"]), ptr(keep["idxB"]), ptr(keep["idxK"]),
+                       ptr(c), ptr(c) + 64, ptr(c) + 128, ptr(c) + 192, ptr(c) + 320)
+        h = C.c_void_p()
+        ctx._chk(ctx.L.dvn_groth16_pk_import(ctx.h, C.byref(ka), C.byref(h)))
+        self.h = h
+
+    def prove_solved(self, w: np.ndarray, a: np.ndarray, b: np.ndarray, c: np.ndarray, r_mont, s_mont) -> dict:
+        w, a, b, c = (np.ascontiguousarray(x, dtype=np.uint64) for x in (w, a, b, c))
+        assert a.shape == b.shape == c.shape
+        r_mont = np.ascontiguousarray(r_mont, dtype=np.uint64); s_mont = np.ascontiguousarray(s_mont, dtype=np.uint64)
+        out = np.zeros(32, dtype=np.uint64)
+        self.ctx._chk(self.ctx.L.dvn_groth16_prove_solved(self.ctx.h, self.h, _host(w), _host(a), _host(b), _host(c), a.shape[0],
+                                                          _host(r_mont), _host(s_mont), _host(out)))
+        return {"Ar": out[0:8].copy(), "Bs": out[8:24].copy(), "Krs": out[24:32].copy()}
 
     def free(self):
         if self.h:

@@ -64,6 +64,10 @@ struct dvn_groth16_pk {
     u32 commit_wire = 0, n_committed = 0, tail = 0;
     std::vector<u32> public_committed;
     dvn_points *Basis = nullptr, *BasisSigma = nullptr;
+    // imported keys (groth16_pk_import: gnark's own ProvingKey arrays): K's scalars are gathered through d_idxK; no R1CS
+    u32 *d_idxK = nullptr, *d_wK = nullptr;
+    size_t nK = 0;
+    bool imported = false;
     // verifying key as gnark affine Montgomery images (uint64 words): alpha (G1) | beta | gamma | delta (G2) | IC[n_public] (G1:
     // CONSTANT, PUB_i of the Solidity verifier) | Pedersen G | Pedersen GSigmaNeg (G2; only with a commitment)
     std::vector<uint64_t> vk_words;
@@ -518,14 +522,20 @@ template <class SU> static int32_t groth16_device(dvn_ctx* ctx, dvn_groth16_pk* 
         TRY(submit_g2(pk->B2, pk->nB, pk->d_wB, &l2));
         TRY(submit_g1(pk->A, pk->nA, pk->d_wA, &lA));
         TRY(submit_g1(pk->B, pk->nB, pk->d_wB, &lB));
-        TRY(submit_g1(pk->K, m - pk->k_first, pk->d_w + pk->k_first * EW, &lK));
+        if (pk->d_idxK) {                                  // imported key: K's wires are an index list (private minus committed)
+            if (pk->nK) k_gather_fr<S::EW><<<(unsigned)((pk->nK + 255) / 256), 256, 0, st>>>(pk->d_w, pk->d_idxK, pk->d_wK, pk->nK);
+            HIP_TRY(hipGetLastError());
+            TRY(submit_g1(pk->K, pk->nK, pk->d_wK, &lK));
+        } else TRY(submit_g1(pk->K, m - pk->k_first, pk->d_w + pk->k_first * EW, &lK));
         // ... while the main stream runs (1) the "solve" a = A w, b = B w, c = C w (zero padded to the domain size) and
         // (3) h = computeH(a, b, c), which stays on the device as the scalar vector of the Z MSM
-        HIP_TRY(hipMemsetAsync(pk->d_abc, 0, 3 * n * EB, st));
-        for (int q = 0; q < 3; ++q)
-            k_r1cs_matvec<S><<<(unsigned)((pk->n_constraints + 127) / 128), 128, 0, st>>>(pk->d_ptr[q], pk->d_idx[q], pk->d_coef[q], pk->d_w,
-                                                                                      pk->d_abc + (size_t)q * n * EW, (u32)pk->n_constraints);
-        HIP_TRY(hipGetLastError());
+        if (!(flags & 4)) {                                // flags & 4: the solver's (a, b, c) already sit zero-padded in pk->d_abc
+            HIP_TRY(hipMemsetAsync(pk->d_abc, 0, 3 * n * EB, st));
+            for (int q = 0; q < 3; ++q)
+                k_r1cs_matvec<S><<<(unsigned)((pk->n_constraints + 127) / 128), 128, 0, st>>>(pk->d_ptr[q], pk->d_idx[q], pk->d_coef[q], pk->d_w,
+                                                                                          pk->d_abc + (size_t)q * n * EW, (u32)pk->n_constraints);
+            HIP_TRY(hipGetLastError());
+        }
         TRY(SU::compute_h(ctx, pk->dom, pk->d_abc, pk->d_abc + n * EW, pk->d_abc + 2 * n * EW));
         HIP_TRY(hipEventRecord(e1, st));
         // Z takes the first lane that frees up: its submit makes the lane wait for computeH
@@ -599,11 +609,98 @@ template <class SU> static int32_t groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* p
     TRY(enter(ctx));
     if (!pk || !witness || !r_mont || !s_mont || !proof_out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (pk->suite != SU::SUITE) return fail(DVN_ERR_INVALID_ARG, "proving key belongs to another curve");
+    if (pk->imported) return fail(DVN_ERR_INVALID_ARG, "imported key: it has no constraint system, prove from the solver's output (prove_solved)");
     const HostKey<SU>& hk = *(const HostKey<SU>*)pk->hk;
     std::lock_guard<std::mutex> lk(ctx->mu);
     Blind<SU> bl(hk, r_mont, s_mont);
     MsmResults<SU> R;
-    TRY(groth16_device<SU>(ctx, pk, witness, flags, 0, 1, &R));
+    TRY(groth16_device<SU>(ctx, pk, witness, flags & 1u, 0, 1, &R));
+    groth16_assemble<SU>(hk, R, bl, proof_out);
+    return DVN_OK;
+}
+
+// ---- keys that come from gnark: the in-memory arrays of a groth16.ProvingKey, handed over once ("hold device
+// handles in a side table keyed by PK pointer") -- the path a node takes with the proving keys it loads at
+// /root/reference/circuits/artifacts.go:391-406.  All point arrays are gnark affine Montgomery images; idxA / idxB / idxK list,
+// in order, the wires whose scalars go with A / B (= B2) / K (gnark drops the points at infinity of A and B -- InfinityA/B --
+// and keeps K for the private, non-committed wires only).
+struct Groth16Import {
+    u32 log_n; size_t m;
+    const uint64_t *A, *B, *K, *Z, *B2; size_t nA, nB, nK, nZ;
+    const u32 *idxA, *idxB, *idxK;
+    const uint64_t *alpha1, *beta1, *delta1, *beta2, *delta2;
+};
+template <class SU> static int32_t groth16_pk_import(dvn_ctx* ctx, const Groth16Import& d, dvn_groth16_pk** out) {
+    typedef typename SU::FrC S;
+    typedef typename SU::G1T G1;
+    typedef typename SU::G2T G2;
+    typedef typename SU::H1 H1;
+    typedef typename SU::H2 H2;
+    constexpr size_t EB = (size_t)S::EW * 4;
+    TRY(enter(ctx));
+    if (!out || !d.A || !d.B || !d.K || !d.Z || !d.B2 || !d.idxA || !d.idxB || !d.idxK || !d.alpha1 || !d.beta1 || !d.delta1 || !d.beta2 || !d.delta2)
+        return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    const size_t n = (size_t)1 << d.log_n;
+    if (d.log_n < 1 || d.log_n > 27 || d.nZ + 1 < n || d.m == 0) return fail(DVN_ERR_INVALID_ARG, "bad sizes: Z must hold at least n - 1 points");
+    for (size_t i = 0; i < d.nA; ++i) if (d.idxA[i] >= d.m) return fail(DVN_ERR_INVALID_ARG, "idxA[%zu] outside the wire vector", i);
+    for (size_t i = 0; i < d.nB; ++i) if (d.idxB[i] >= d.m) return fail(DVN_ERR_INVALID_ARG, "idxB[%zu] outside the wire vector", i);
+    for (size_t i = 0; i < d.nK; ++i) if (d.idxK[i] >= d.m) return fail(DVN_ERR_INVALID_ARG, "idxK[%zu] outside the wire vector", i);
+    dvn_groth16_pk* pk = new (std::nothrow) dvn_groth16_pk();
+    if (!pk) return fail(DVN_ERR_OOM, "host allocation failed");
+    pk->suite = SU::SUITE; pk->imported = true;
+    pk->log_n = d.log_n; pk->n = n; pk->m = d.m; pk->n_public = 0; pk->n_constraints = n; pk->nA = d.nA; pk->nB = d.nB; pk->nK = d.nK; pk->k_first = d.m - d.nK;
+    auto body = [&]() -> int32_t {
+        TRY(SU::domain_create(ctx, d.log_n, &pk->dom));
+        TRY((points_upload<G1>(ctx, d.A, d.nA, 1, &pk->A)));
+        TRY((points_upload<G1>(ctx, d.B, d.nB, 1, &pk->B)));
+        TRY((points_upload<G1>(ctx, d.K, d.nK, 1, &pk->K)));
+        TRY((points_upload<G1>(ctx, d.Z, d.nZ, 1, &pk->Z)));
+        TRY((points_upload<G2>(ctx, d.B2, d.nB, 2, &pk->B2)));
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        auto up = [&](u32** dst, const u32* src, size_t cnt) -> int32_t {
+            HIP_TRY(hipMalloc((void**)dst, (cnt ? cnt : 1) * 4));
+            if (cnt) HIP_TRY(hipMemcpy(*dst, src, cnt * 4, hipMemcpyHostToDevice));
+            return DVN_OK;
+        };
+        TRY(up(&pk->d_idxA, d.idxA, d.nA)); TRY(up(&pk->d_idxB, d.idxB, d.nB)); TRY(up(&pk->d_idxK, d.idxK, d.nK));
+        HIP_TRY(hipMalloc((void**)&pk->d_w, d.m * EB));
+        HIP_TRY(hipMalloc((void**)&pk->d_abc, 3 * n * EB));
+        HIP_TRY(hipMalloc((void**)&pk->d_wA, (d.nA ? d.nA : 1) * EB));
+        HIP_TRY(hipMalloc((void**)&pk->d_wB, (d.nB ? d.nB : 1) * EB));
+        HIP_TRY(hipMalloc((void**)&pk->d_wK, (d.nK ? d.nK : 1) * EB));
+        HostKey<SU>* hk = new HostKey<SU>();
+        pk->hk = hk; pk->hk_free = [](void* p) { delete (HostKey<SU>*)p; };
+        auto ld1 = [](const uint64_t* w) { u32 img[G1::AW]; G1::store_affine_internal(G1::affine_from_ext((const u32*)w), img); return H1::load_device_affine(img); };
+        auto ld2 = [](const uint64_t* w) { u32 img[G2::AW]; G2::store_affine_internal(G2::affine_from_ext((const u32*)w), img); return H2::load_device_affine(img); };
+        hk->alpha = ld1(d.alpha1); hk->beta = ld1(d.beta1); hk->delta = ld1(d.delta1); hk->beta2 = ld2(d.beta2); hk->delta2 = ld2(d.delta2);
+        return DVN_OK;
+    };
+    int32_t rc = body();
+    if (rc != DVN_OK) { std::string keep = tl_error; (void)dvn_groth16_pk_free(ctx, pk); tl_error = keep; return rc; }
+    *out = pk;
+    return DVN_OK;
+}
+// Prove from the solver's output (gnark: `solution.W`, `solution.A/B/C`): w = m wire values, a / b / c = len <= n values each.
+// Everything after the solve of row a10 runs here: computeH, the filtered MSMs on four lanes, blinding, assembly.
+template <class SU> static int32_t groth16_prove_solved(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b,
+                                                        const uint64_t* c, size_t len, const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out) {
+    typedef typename SU::FrC S;
+    constexpr size_t EB = (size_t)S::EW * 4;
+    TRY(enter(ctx));
+    if (!pk || !w || !a || !b || !c || !r_mont || !s_mont || !proof_out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    if (pk->suite != SU::SUITE) return fail(DVN_ERR_INVALID_ARG, "proving key belongs to another curve");
+    if (len > pk->n) return fail(DVN_ERR_INVALID_ARG, "len = %zu exceeds the domain size %zu", len, pk->n);
+    const HostKey<SU>& hk = *(const HostKey<SU>*)pk->hk;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    Blind<SU> bl(hk, r_mont, s_mont);
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(pk->d_w, w, pk->m * EB, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(pk->d_abc, 0, 3 * pk->n * EB, st));
+    const uint64_t* src[3] = {a, b, c};
+    for (int q = 0; q < 3; ++q) if (len) HIP_TRY(hipMemcpyAsync(pk->d_abc + (size_t)q * pk->n * S::EW, src[q], len * EB, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));                     // the caller's buffers are free on return (cgo rule), uploads done
+    MsmResults<SU> R;
+    TRY(groth16_device<SU>(ctx, pk, (const uint64_t*)pk->d_w, 1u | 2u | 4u, 0, 1, &R));
     groth16_assemble<SU>(hk, R, bl, proof_out);
     return DVN_OK;
 }
@@ -622,9 +719,10 @@ template <class SU> static int32_t groth16_prove_shard(dvn_ctx* ctx, dvn_groth16
     if (!pk || !witness || !partial_out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (pk->suite != SU::SUITE) return fail(DVN_ERR_INVALID_ARG, "proving key belongs to another curve");
     if (world < 1 || world > 64 || rank >= world) return fail(DVN_ERR_INVALID_ARG, "rank %u outside world %u", rank, world);
+    if (pk->imported) return fail(DVN_ERR_INVALID_ARG, "imported key: it has no constraint system");
     std::lock_guard<std::mutex> lk(ctx->mu);
     MsmResults<SU> R;
-    TRY(groth16_device<SU>(ctx, pk, witness, flags, rank, world, &R));
+    TRY(groth16_device<SU>(ctx, pk, witness, flags & 1u, rank, world, &R));
     constexpr size_t J1 = PartialLayout<SU>::J1;
     H1::write_jac(R.mA, partial_out); H1::write_jac(R.mB, partial_out + J1); H1::write_jac(R.mK, partial_out + 2 * J1);
     H1::write_jac(R.mZ, partial_out + 3 * J1); H2::write_jac(R.mB2, partial_out + 4 * J1);

@@ -306,6 +306,30 @@ int32_t dvn_bw6761_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_
  * keccak256(C.x || C.y || publicCommitted) mod r that the reference's Solidity verifier recomputes
  * (statetransition_vkey.sol:659-676), the completion of the witness, then the proof as dvn_groth16_prove.
  * Together with dvn_groth16_proof_abi_encode this yields the calldata of solidity/solidity.go:85-116. */
+/* ---- gnark's own proving key (device handles in a side table keyed by the PK pointer) --------------------
+ * dvn_groth16_pk_import takes the in-memory arrays of a *groth16_bn254.ProvingKey as the node loads it
+ * (/root/reference/circuits/artifacts.go:391-406; zero-copy from the Go slices, copied to HBM before return): G1.A / G1.B /
+ * G1.K / G1.Z / G2.B as gnark affine Montgomery images, the wire indices that go with A, B (= G2.B) and K in order (gnark
+ * drops InfinityA / InfinityB points and keeps K for the private, non-committed wires), and the five key constants.
+ * dvn_groth16_prove_solved then runs everything of groth16.Prove that follows the solver (row a10 steps (3)-(7)): w = all
+ * wire values, a / b / c = the solver's constraint evaluations (len <= 2^log_n each, zero padded here). */
+typedef struct dvn_groth16_key_arrays {
+    uint32_t log_n;              /* domain size 2^log_n */
+    uint64_t n_wires;            /* m */
+    const uint64_t *A, *B, *K, *Z, *B2;          /* nA x 8, nB x 8, nK x 8, nZ x 8, nB x 16 uint64 */
+    uint64_t nA, nB, nK, nZ;                     /* nZ >= 2^log_n - 1 */
+    const uint32_t *idxA, *idxB, *idxK;          /* nA, nB, nK wire indices */
+    const uint64_t *alpha_g1, *beta_g1, *delta_g1;   /* 8 uint64 each */
+    const uint64_t *beta_g2, *delta_g2;              /* 16 uint64 each */
+} dvn_groth16_key_arrays;
+int32_t dvn_groth16_pk_import(dvn_ctx* ctx, const dvn_groth16_key_arrays* key, dvn_groth16_pk** out);
+int32_t dvn_groth16_prove_solved(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b,
+                                 const uint64_t* c, size_t len, const uint64_t r_mont[4], const uint64_t s_mont[4],
+                                 uint64_t proof_out[32]);
+/* arrays of a key built by dvn_groth16_setup in the import layout: which = 0..4 A, B, K, Z, B2; 5 / 6 idxA / idxB (uint32);
+ * 7 the constants alpha1 | beta1 | delta1 | beta2 | delta2.  out = NULL queries the size in uint64 words. */
+int32_t dvn_groth16_pk_export_arrays(dvn_ctx* ctx, const dvn_groth16_pk* pk, int which, uint64_t* out, size_t cap_words, size_t* n_words);
+
 /* The verifying key of a Setup (the reference's Setup returns (pk, vk), /root/reference/prover/setup.go:15-28) as affine
  * Montgomery images of the key's curve: alpha (G1) | beta, gamma, delta (G2) | IC[n_public] (G1: CONSTANT and PUB_i of the
  * generated Solidity verifier) | with a commitment: Pedersen G, GSigmaNeg (G2).  out = NULL queries the size. */

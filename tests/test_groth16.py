@@ -221,3 +221,38 @@ def test_groth16_with_commitment_trapdoor_identity(ctx, pkg, opy, n_constraints,
     with pytest.raises(pkg.DvnError):
         key0.prove_committed(cs0.witness(), mont(o, 1), mont(o, 2))
     key0.free(); cs0.free()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# gnark's own key handed over as arrays + proofs from the solver's output (the drop-in path for the keys the node
+# loads at circuits/artifacts.go:391-406): export -> import round trip must reproduce the proof bit for bit.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_constraints", [(1 << 12) - 7, 1 << 16])
+def test_imported_key_proves_from_solver_output(ctx, pkg, opy, orc, n_constraints):
+    o = opy
+    cs = pkg.R1CS(7, n_constraints, 9)
+    key = pkg.Groth16Key(ctx, cs, 3)
+    arrays = key.export_arrays(cs.n_wires, cs.n_public)
+    assert arrays["A"].shape[0] == key.sizes["A"] and arrays["B2"].shape == (key.sizes["B"], 16) and arrays["Z"].shape[0] == 1 << key.log_n
+    ik = pkg.ImportedKey(ctx, key.log_n, cs.n_wires, arrays)
+    ref = o.SyntheticR1CS(n_constraints, 9, 7)
+    a, b, c = (np.array([o.limbs(o.to_mont(v, R)) for v in col], dtype=np.uint64) for col in ref.abc())   # the solver's output
+    r, s = mont(o, 1234567), mont(o, 7654321)
+    got = ik.prove_solved(cs.witness(), a, b, c, r, s)
+    want = key.prove(cs.witness(), r, s)
+    _, closed = orc.groth16_synthetic_expected(7, n_constraints, 9, 3, r, s)
+    for k in ("Ar", "Bs", "Krs"):
+        assert (got[k] == want[k]).all() and (got[k] == closed[k]).all(), k
+    # an imported key has no constraint system: the R1CS entry points refuse it; oversized solver output is rejected
+    out = np.zeros(32, dtype=np.uint64)
+    w = cs.witness()
+    rc = ctx.L.dvn_groth16_prove(ctx.h, ik.h, w.ctypes.data, 0, r.ctypes.data, s.ctypes.data, out.ctypes.data)
+    assert rc == -1
+    big = np.zeros(((1 << key.log_n) + 1, 4), dtype=np.uint64)
+    with pytest.raises(pkg.DvnError):
+        ik.prove_solved(w, big, big, big, r, s)
+    bad = dict(arrays); bad["idxA"] = arrays["idxA"].copy(); bad["idxA"][0] = cs.n_wires
+    with pytest.raises(pkg.DvnError):
+        pkg.ImportedKey(ctx, key.log_n, cs.n_wires, bad)
+    ik.free(); key.free(); cs.free()
