@@ -492,7 +492,8 @@ template <class SU> struct MsmResults { typename SU::H1::X mA, mB, mK, mZ; typen
 // this rank's slice of the ROWS of every (expanded) key set -- the partial results of all ranks add up to the MSMs; the
 // "solve" and computeH are replicated on every rank.  Caller holds ctx->mu.
 template <class SU> static int32_t groth16_device(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
-                                                  u32 rank, u32 world, MsmResults<SU>* out) {
+                                                  u32 rank, u32 world, MsmResults<SU>* out,
+                                                  const uint64_t* const* abc_host = nullptr, size_t abc_len = 0) {
     typedef typename SU::FrC S;
     constexpr u32 EW = S::EW;
     constexpr size_t EB = (size_t)EW * 4;
@@ -529,7 +530,11 @@ template <class SU> static int32_t groth16_device(dvn_ctx* ctx, dvn_groth16_pk* 
         } else TRY(submit_g1(pk->K, m - pk->k_first, pk->d_w + pk->k_first * EW, &lK));
         // ... while the main stream runs (1) the "solve" a = A w, b = B w, c = C w (zero padded to the domain size) and
         // (3) h = computeH(a, b, c), which stays on the device as the scalar vector of the Z MSM
-        if (!(flags & 4)) {                                // flags & 4: the solver's (a, b, c) already sit zero-padded in pk->d_abc
+        if (abc_host) {                                    // the solver's (a, b, c) from host memory: their upload runs under the wire-only MSMs
+            HIP_TRY(hipMemsetAsync(pk->d_abc, 0, 3 * n * EB, st));
+            for (int q = 0; q < 3; ++q)
+                if (abc_len) HIP_TRY(hipMemcpyAsync(pk->d_abc + (size_t)q * n * EW, abc_host[q], abc_len * EB, hipMemcpyHostToDevice, st));
+        } else if (!(flags & 4)) {                         // flags & 4: (a, b, c) already sit zero-padded in pk->d_abc
             HIP_TRY(hipMemsetAsync(pk->d_abc, 0, 3 * n * EB, st));
             for (int q = 0; q < 3; ++q)
                 k_r1cs_matvec<S><<<(unsigned)((pk->n_constraints + 127) / 128), 128, 0, st>>>(pk->d_ptr[q], pk->d_idx[q], pk->d_coef[q], pk->d_w,
@@ -693,14 +698,11 @@ template <class SU> static int32_t groth16_prove_solved(dvn_ctx* ctx, dvn_groth1
     const HostKey<SU>& hk = *(const HostKey<SU>*)pk->hk;
     std::lock_guard<std::mutex> lk(ctx->mu);
     Blind<SU> bl(hk, r_mont, s_mont);
-    hipStream_t st = ctx->stream;
-    HIP_TRY(hipMemcpyAsync(pk->d_w, w, pk->m * EB, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(pk->d_abc, 0, 3 * pk->n * EB, st));
+    // w goes up first (the four wire-only MSMs start on it), a / b / c follow while those run; every copy has completed when
+    // groth16_device returns (it synchronises), so the caller's buffers are free on return (cgo rule)
     const uint64_t* src[3] = {a, b, c};
-    for (int q = 0; q < 3; ++q) if (len) HIP_TRY(hipMemcpyAsync(pk->d_abc + (size_t)q * pk->n * S::EW, src[q], len * EB, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));                     // the caller's buffers are free on return (cgo rule), uploads done
     MsmResults<SU> R;
-    TRY(groth16_device<SU>(ctx, pk, (const uint64_t*)pk->d_w, 1u | 2u | 4u, 0, 1, &R));
+    TRY(groth16_device<SU>(ctx, pk, w, 0u, 0, 1, &R, src, len));
     groth16_assemble<SU>(hk, R, bl, proof_out);
     return DVN_OK;
 }
