@@ -123,6 +123,15 @@ def load_library():
         "dvn_groth16_pk_import": (i32, [vp, vp, C.POINTER(vp)]),
         "dvn_groth16_prove_solved": (i32, [vp, vp, vp, vp, vp, vp, sz, vp, vp, vp]),
         "dvn_groth16_pk_export_arrays": (i32, [vp, vp, C.c_int, vp, sz, C.POINTER(sz)]),
+        "dvn_bls12377_groth16_pk_import": (i32, [vp, vp, C.POINTER(vp)]),
+        "dvn_bls12377_groth16_prove_solved": (i32, [vp, vp, vp, vp, vp, vp, sz, vp, vp, vp]),
+        "dvn_bls12377_groth16_pk_export_arrays": (i32, [vp, vp, C.c_int, vp, sz, C.POINTER(sz)]),
+        "dvn_bls12381_groth16_pk_import": (i32, [vp, vp, C.POINTER(vp)]),
+        "dvn_bls12381_groth16_prove_solved": (i32, [vp, vp, vp, vp, vp, vp, sz, vp, vp, vp]),
+        "dvn_bls12381_groth16_pk_export_arrays": (i32, [vp, vp, C.c_int, vp, sz, C.POINTER(sz)]),
+        "dvn_bw6761_groth16_pk_import": (i32, [vp, vp, C.POINTER(vp)]),
+        "dvn_bw6761_groth16_prove_solved": (i32, [vp, vp, vp, vp, vp, vp, sz, vp, vp, vp]),
+        "dvn_bw6761_groth16_pk_export_arrays": (i32, [vp, vp, C.c_int, vp, sz, C.POINTER(sz)]),
         "dvn_r1cs_synthetic_committed": (i32, [u64, u32, u32, u32, C.POINTER(vp)]),
         "dvn_groth16_prove_committed": (i32, [vp, vp, vp, u32, vp, vp, vp, vp, vp, vp]),
         "dvn_keccak256": (i32, [vp, sz, vp]),
@@ -178,6 +187,7 @@ EXPORTED_SYMBOLS = [
     "dvn_bls12381_scalars_synthetic", "dvn_bls12381_msm_g1", "dvn_bls12381_msm_g2", "dvn_bls12381_ntt_domain", "dvn_bls12381_ntt", "dvn_bls12381_groth16_compute_h",
     "dvn_bls12381_r1cs_synthetic", "dvn_bls12381_groth16_setup", "dvn_bls12381_groth16_prove", "dvn_r1cs_curve",
     "dvn_r1cs_synthetic_committed", "dvn_groth16_prove_committed", "dvn_keccak256", "dvn_groth16_vk_export", "dvn_groth16_pk_import", "dvn_groth16_prove_solved", "dvn_groth16_pk_export_arrays",
+    "dvn_bls12377_groth16_pk_import", "dvn_bls12377_groth16_prove_solved", "dvn_bls12377_groth16_pk_export_arrays", "dvn_bls12381_groth16_pk_import", "dvn_bls12381_groth16_prove_solved", "dvn_bls12381_groth16_pk_export_arrays", "dvn_bw6761_groth16_pk_import", "dvn_bw6761_groth16_prove_solved", "dvn_bw6761_groth16_pk_export_arrays",
     "dvn_kzg_setup_load", "dvn_kzg_setup_free", "dvn_kzg_blob_to_commitment", "dvn_kzg_compute_proof", "dvn_kzg_compute_cell_proofs",
     "dvn_kzg_evaluate_barycentric", "dvn_kzg_compute_blob_proof", "dvn_sha256",
     "dvn_bw6761_points_upload", "dvn_bw6761_points_synthetic", "dvn_bw6761_points_download", "dvn_bw6761_scalars_synthetic", "dvn_bw6761_msm",
@@ -493,15 +503,17 @@ class Groth16Key:
         return vk
 
     def export_arrays(self, n_wires: int, n_public: int) -> dict:
-        """The key's arrays in the layout dvn_groth16_pk_import takes (BN254 keys without commitment)."""
+        """The key's arrays in the layout dvn_<curve>_groth16_pk_import takes (keys without commitment)."""
+        fn = getattr(self.ctx.L, self._prefix + "groth16_pk_export_arrays")
+        a1, a2 = self._a1, self._a2
         def get(which, dtype=np.uint64):
             n = C.c_size_t()
-            self.ctx._chk(self.ctx.L.dvn_groth16_pk_export_arrays(self.ctx.h, self.h, which, None, 0, C.byref(n)))
+            self.ctx._chk(fn(self.ctx.h, self.h, which, None, 0, C.byref(n)))
             out = np.zeros(max(n.value, 1), dtype=np.uint64)
-            self.ctx._chk(self.ctx.L.dvn_groth16_pk_export_arrays(self.ctx.h, self.h, which, _host(out), out.size, C.byref(n)))
+            self.ctx._chk(fn(self.ctx.h, self.h, which, _host(out), out.size, C.byref(n)))
             return out[:n.value]
-        arr = {"A": get(0).reshape(-1, 8), "B": get(1).reshape(-1, 8), "K": get(2).reshape(-1, 8), "Z": get(3).reshape(-1, 8),
-               "B2": get(4).reshape(-1, 16), "consts": get(7)}
+        arr = {"A": get(0).reshape(-1, a1), "B": get(1).reshape(-1, a1), "K": get(2).reshape(-1, a1), "Z": get(3).reshape(-1, a1),
+               "B2": get(4).reshape(-1, a2), "consts": get(7)}
         arr["idxA"] = get(5).view(np.uint32)[:self.sizes["A"]].copy()
         arr["idxB"] = get(6).view(np.uint32)[:self.sizes["B"]].copy()
         arr["idxK"] = np.arange(n_public, n_wires, dtype=np.uint32)
@@ -562,8 +574,11 @@ class ImportedKey:
     """A gnark proving key handed over as arrays (dvn_groth16_pk_import); proofs come from the solver's output
     (dvn_groth16_prove_solved).  arrays: dict with A, B, K, Z (n,8), B2 (n,16) uint64; idxA, idxB, idxK uint32; consts (56,) uint64."""
 
-    def __init__(self, ctx: "Context", log_n: int, n_wires: int, arrays: dict):
+    def __init__(self, ctx: "Context", log_n: int, n_wires: int, arrays: dict, curve: str = "bn254"):
         self.ctx = ctx
+        self._prefix = "dvn_" if curve == "bn254" else f"dvn_{curve}_"
+        self._a1 = {"bn254": 8, "bw6761": 24}.get(curve, 12)
+        self._a2 = self._a1 if curve == "bw6761" else 2 * self._a1
         keep = {k: np.ascontiguousarray(arrays[k], dtype=np.uint64) for k in ("A", "B", "K", "Z", "B2", "consts")}
         keep.update({k: np.ascontiguousarray(arrays[k], dtype=np.uint32) for k in ("idxA", "idxB", "idxK")})
         c = keep["consts"]
@@ -571,19 +586,20 @@ class ImportedKey:
         ka = KeyArrays(log_n, n_wires, ptr(keep["A"]), ptr(keep["B"]), ptr(keep["K"]), ptr(keep["Z"]), ptr(keep["B2"]),
                        keep["A"].shape[0], keep["B"].shape[0], keep["K"].shape[0], keep["Z"].shape[0],
                        ptr(keep["idxA"]), ptr(keep["idxB"]), ptr(keep["idxK"]),
-                       ptr(c), ptr(c) + 64, ptr(c) + 128, ptr(c) + 192, ptr(c) + 320)
+                       ptr(c), ptr(c) + 8 * self._a1, ptr(c) + 16 * self._a1, ptr(c) + 24 * self._a1, ptr(c) + 24 * self._a1 + 8 * self._a2)
         h = C.c_void_p()
-        ctx._chk(ctx.L.dvn_groth16_pk_import(ctx.h, C.byref(ka), C.byref(h)))
+        ctx._chk(getattr(ctx.L, self._prefix + "groth16_pk_import")(ctx.h, C.byref(ka), C.byref(h)))
         self.h = h
 
     def prove_solved(self, w: np.ndarray, a: np.ndarray, b: np.ndarray, c: np.ndarray, r_mont, s_mont) -> dict:
         w, a, b, c = (np.ascontiguousarray(x, dtype=np.uint64) for x in (w, a, b, c))
         assert a.shape == b.shape == c.shape
         r_mont = np.ascontiguousarray(r_mont, dtype=np.uint64); s_mont = np.ascontiguousarray(s_mont, dtype=np.uint64)
-        out = np.zeros(32, dtype=np.uint64)
-        self.ctx._chk(self.ctx.L.dvn_groth16_prove_solved(self.ctx.h, self.h, _host(w), _host(a), _host(b), _host(c), a.shape[0],
-                                                          _host(r_mont), _host(s_mont), _host(out)))
-        return {"Ar": out[0:8].copy(), "Bs": out[8:24].copy(), "Krs": out[24:32].copy()}
+        a1, a2 = self._a1, self._a2
+        out = np.zeros(2 * a1 + a2, dtype=np.uint64)
+        self.ctx._chk(getattr(self.ctx.L, self._prefix + "groth16_prove_solved")(self.ctx.h, self.h, _host(w), _host(a), _host(b), _host(c), a.shape[0],
+                                                                                 _host(r_mont), _host(s_mont), _host(out)))
+        return {"Ar": out[0:a1].copy(), "Bs": out[a1:a1 + a2].copy(), "Krs": out[a1 + a2:2 * a1 + a2].copy()}
 
     def free(self):
         if self.h:

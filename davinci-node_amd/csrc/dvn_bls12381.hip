@@ -80,5 +80,15 @@ extern "C" int32_t dvn_bls12381_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, 
     return groth16_prove<SuiteBls12381>(ctx, pk, witness, flags, r_mont, s_mont, proof_out);
 }
 
+// gnark's own key arrays + proofs from the solver's output on this curve (see dvn_groth16_pk_import / dvn_groth16_prove_solved)
+extern "C" int32_t dvn_bls12381_groth16_pk_import(dvn_ctx* ctx, const dvn_groth16_key_arrays* k, dvn_groth16_pk** out) { return groth16_pk_import_api<SuiteBls12381>(ctx, k, out); }
+extern "C" int32_t dvn_bls12381_groth16_prove_solved(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b, const uint64_t* c, size_t len,
+                                              const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out) {
+    return groth16_prove_solved<SuiteBls12381>(ctx, pk, w, a, b, c, len, r_mont, s_mont, proof_out);
+}
+extern "C" int32_t dvn_bls12381_groth16_pk_export_arrays(dvn_ctx* ctx, const dvn_groth16_pk* pk, int which, uint64_t* out, size_t cap_words, size_t* n_words) {
+    return groth16_pk_export_arrays<SuiteBls12381>(ctx, pk, which, out, cap_words, n_words);
+}
+
 // ---- blob KZG (EIP-4844 / EIP-7594) on this curve: SURVEY.md row f3 ----------------------------------------------------
 #include "kzg_impl.h"

@@ -4,7 +4,6 @@
 // dvn_msm_g2.hip and dvn_ntt.hip (cross-TU calls: the kernels are not instantiated a second time here).
 #include "groth16_impl.h"
 
-int32_t dvn_internal_points_download_g2(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, uint64_t* xy);   // dvn_msm_g2.hip
 
 struct SuiteBn254 {
     typedef FrCfg FrC;
@@ -88,51 +87,13 @@ extern "C" int32_t dvn_groth16_pk_info(const dvn_groth16_pk* pk, uint32_t* log_n
 }
 
 // ---- gnark's own proving key, handed over once; then proofs from the solver's output -------------------------------------------
-extern "C" int32_t dvn_groth16_pk_import(dvn_ctx* ctx, const dvn_groth16_key_arrays* k, dvn_groth16_pk** out) {
-    if (!k) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
-    Groth16Import d{k->log_n, (size_t)k->n_wires, k->A, k->B, k->K, k->Z, k->B2, (size_t)k->nA, (size_t)k->nB, (size_t)k->nK, (size_t)k->nZ,
-                    k->idxA, k->idxB, k->idxK, k->alpha_g1, k->beta_g1, k->delta_g1, k->beta_g2, k->delta_g2};
-    return groth16_pk_import<SuiteBn254>(ctx, d, out);
-}
+extern "C" int32_t dvn_groth16_pk_import(dvn_ctx* ctx, const dvn_groth16_key_arrays* k, dvn_groth16_pk** out) { return groth16_pk_import_api<SuiteBn254>(ctx, k, out); }
 extern "C" int32_t dvn_groth16_prove_solved(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b,
                                             const uint64_t* c, size_t len, const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32]) {
     return groth16_prove_solved<SuiteBn254>(ctx, pk, w, a, b, c, len, r_mont, s_mont, proof_out);
 }
-// the arrays of a key built by dvn_groth16_setup, in the layout dvn_groth16_pk_import takes (tests: export -> import round trip)
 extern "C" int32_t dvn_groth16_pk_export_arrays(dvn_ctx* ctx, const dvn_groth16_pk* pk, int which, uint64_t* out, size_t cap_words, size_t* n_words) {
-    TRY(enter(ctx));
-    if (!pk || !n_words) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
-    if (pk->suite != 0) return fail(DVN_ERR_UNSUPPORTED, "BN254 keys only");
-    typedef dvn_host::HG1 H1; typedef dvn_host::HG2 H2;
-    const HostKey<SuiteBn254>& hk = *(const HostKey<SuiteBn254>*)pk->hk;
-    const dvn_points* sets[5] = {pk->A, pk->B, pk->K, pk->Z, pk->B2};
-    if (which >= 0 && which < 5) {
-        const size_t per = which == 4 ? 16 : 8, cnt = sets[which]->n;
-        *n_words = cnt * per;
-        if (!out) return DVN_OK;
-        if (cap_words < cnt * per) return fail(DVN_ERR_INVALID_ARG, "buffer too small");
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        return which == 4 ? dvn_internal_points_download_g2(ctx, sets[4], 0, cnt, out) : points_download<G1>(ctx, sets[which], 0, cnt, out);
-    }
-    if (which == 5 || which == 6) {                          // wire index lists of A / B (uint32 packed into the uint64 buffer)
-        const size_t cnt = which == 5 ? pk->nA : pk->nB;
-        *n_words = (cnt + 1) / 2;
-        if (!out) return DVN_OK;
-        if (cap_words < (cnt + 1) / 2) return fail(DVN_ERR_INVALID_ARG, "buffer too small");
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        HIP_TRY(hipMemcpy(out, which == 5 ? pk->d_idxA : pk->d_idxB, cnt * 4, hipMemcpyDeviceToHost));
-        return DVN_OK;
-    }
-    if (which == 7) {                                        // alpha1 | beta1 | delta1 (8 each) | beta2 | delta2 (16 each)
-        *n_words = 56;
-        if (!out) return DVN_OK;
-        if (cap_words < 56) return fail(DVN_ERR_INVALID_ARG, "buffer too small");
-        uint64_t j[24];
-        H1::write_jac(hk.alpha, j); memcpy(out, j, 64); H1::write_jac(hk.beta, j); memcpy(out + 8, j, 64); H1::write_jac(hk.delta, j); memcpy(out + 16, j, 64);
-        H2::write_jac(hk.beta2, j); memcpy(out + 24, j, 128); H2::write_jac(hk.delta2, j); memcpy(out + 40, j, 128);
-        return DVN_OK;
-    }
-    return fail(DVN_ERR_INVALID_ARG, "which must be 0..7");
+    return groth16_pk_export_arrays<SuiteBn254>(ctx, pk, which, out, cap_words, n_words);
 }
 
 // The verifying key Setup produced next to the proving key (groth16.Setup returns both, /root/reference/prover/setup.go:15-28),

@@ -685,6 +685,53 @@ template <class SU> static int32_t groth16_pk_import(dvn_ctx* ctx, const Groth16
     *out = pk;
     return DVN_OK;
 }
+template <class SU> static int32_t groth16_pk_import_api(dvn_ctx* ctx, const dvn_groth16_key_arrays* k, dvn_groth16_pk** out) {
+    if (!k) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    Groth16Import d{k->log_n, (size_t)k->n_wires, k->A, k->B, k->K, k->Z, k->B2, (size_t)k->nA, (size_t)k->nB, (size_t)k->nK, (size_t)k->nZ,
+                    k->idxA, k->idxB, k->idxK, k->alpha_g1, k->beta_g1, k->delta_g1, k->beta_g2, k->delta_g2};
+    return groth16_pk_import<SU>(ctx, d, out);
+}
+// The arrays of a key built by groth16_setup in the layout groth16_pk_import takes (tests: export -> import round trip):
+// which = 0..4 A, B, K, Z, B2; 5 / 6 idxA / idxB (uint32 packed); 7 alpha1 | beta1 | delta1 | beta2 | delta2.
+template <class SU> static int32_t groth16_pk_export_arrays(dvn_ctx* ctx, const dvn_groth16_pk* pk, int which, uint64_t* out, size_t cap_words, size_t* n_words) {
+    typedef typename SU::G1T G1;
+    typedef typename SU::G2T G2;
+    typedef typename SU::H1 H1;
+    typedef typename SU::H2 H2;
+    constexpr size_t A1 = G1::AW / 2, A2 = G2::AW / 2;
+    TRY(enter(ctx));
+    if (!pk || !n_words) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    if (pk->suite != SU::SUITE) return fail(DVN_ERR_INVALID_ARG, "proving key belongs to another curve");
+    const HostKey<SU>& hk = *(const HostKey<SU>*)pk->hk;
+    const dvn_points* sets[5] = {pk->A, pk->B, pk->K, pk->Z, pk->B2};
+    if (which >= 0 && which < 5) {
+        const size_t per = which == 4 ? A2 : A1, cnt = sets[which]->n;
+        *n_words = cnt * per;
+        if (!out) return DVN_OK;
+        if (cap_words < cnt * per) return fail(DVN_ERR_INVALID_ARG, "buffer too small");
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        return which == 4 ? points_download<G2>(ctx, sets[4], 0, cnt, out) : points_download<G1>(ctx, sets[which], 0, cnt, out);
+    }
+    if (which == 5 || which == 6) {
+        const size_t cnt = which == 5 ? pk->nA : pk->nB;
+        *n_words = (cnt + 1) / 2;
+        if (!out) return DVN_OK;
+        if (cap_words < (cnt + 1) / 2) return fail(DVN_ERR_INVALID_ARG, "buffer too small");
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        HIP_TRY(hipMemcpy(out, which == 5 ? pk->d_idxA : pk->d_idxB, cnt * 4, hipMemcpyDeviceToHost));
+        return DVN_OK;
+    }
+    if (which == 7) {
+        *n_words = 3 * A1 + 2 * A2;
+        if (!out) return DVN_OK;
+        if (cap_words < 3 * A1 + 2 * A2) return fail(DVN_ERR_INVALID_ARG, "buffer too small");
+        uint64_t j1[3 * A1 / 2 + 1], j2[3 * A2 / 2 + 1];
+        H1::write_jac(hk.alpha, j1); memcpy(out, j1, A1 * 8); H1::write_jac(hk.beta, j1); memcpy(out + A1, j1, A1 * 8); H1::write_jac(hk.delta, j1); memcpy(out + 2 * A1, j1, A1 * 8);
+        H2::write_jac(hk.beta2, j2); memcpy(out + 3 * A1, j2, A2 * 8); H2::write_jac(hk.delta2, j2); memcpy(out + 3 * A1 + A2, j2, A2 * 8);
+        return DVN_OK;
+    }
+    return fail(DVN_ERR_INVALID_ARG, "which must be 0..7");
+}
 // Prove from the solver's output (gnark: `solution.W`, `solution.A/B/C`): w = m wire values, a / b / c = len <= n values each.
 // Everything after the solve of row a10 runs here: computeH, the filtered MSMs on four lanes, blinding, assembly.
 template <class SU> static int32_t groth16_prove_solved(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b,

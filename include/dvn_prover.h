@@ -330,6 +330,21 @@ int32_t dvn_groth16_prove_solved(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_
  * 7 the constants alpha1 | beta1 | delta1 | beta2 | delta2.  out = NULL queries the size in uint64 words. */
 int32_t dvn_groth16_pk_export_arrays(dvn_ctx* ctx, const dvn_groth16_pk* pk, int which, uint64_t* out, size_t cap_words, size_t* n_words);
 
+/* the same three entry points on the other curves of prover_gpu.go's dispatch (element widths of that curve: G1 12 / 12 / 24,
+ * G2 24 / 24 / 24 uint64 per affine point, scalars 4 / 4 / 6 uint64) */
+int32_t dvn_bls12377_groth16_pk_import(dvn_ctx* ctx, const dvn_groth16_key_arrays* key, dvn_groth16_pk** out);
+int32_t dvn_bls12377_groth16_prove_solved(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b,
+                                          const uint64_t* c, size_t len, const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out);
+int32_t dvn_bls12377_groth16_pk_export_arrays(dvn_ctx* ctx, const dvn_groth16_pk* pk, int which, uint64_t* out, size_t cap_words, size_t* n_words);
+int32_t dvn_bls12381_groth16_pk_import(dvn_ctx* ctx, const dvn_groth16_key_arrays* key, dvn_groth16_pk** out);
+int32_t dvn_bls12381_groth16_prove_solved(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b,
+                                          const uint64_t* c, size_t len, const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out);
+int32_t dvn_bls12381_groth16_pk_export_arrays(dvn_ctx* ctx, const dvn_groth16_pk* pk, int which, uint64_t* out, size_t cap_words, size_t* n_words);
+int32_t dvn_bw6761_groth16_pk_import(dvn_ctx* ctx, const dvn_groth16_key_arrays* key, dvn_groth16_pk** out);
+int32_t dvn_bw6761_groth16_prove_solved(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b,
+                                        const uint64_t* c, size_t len, const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out);
+int32_t dvn_bw6761_groth16_pk_export_arrays(dvn_ctx* ctx, const dvn_groth16_pk* pk, int which, uint64_t* out, size_t cap_words, size_t* n_words);
+
 /* The verifying key of a Setup (the reference's Setup returns (pk, vk), /root/reference/prover/setup.go:15-28) as affine
  * Montgomery images of the key's curve: alpha (G1) | beta, gamma, delta (G2) | IC[n_public] (G1: CONSTANT and PUB_i of the
  * generated Solidity verifier) | with a commitment: Pedersen G, GSigmaNeg (G2).  out = NULL queries the size. */

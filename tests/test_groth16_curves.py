@@ -101,3 +101,27 @@ def test_groth16_trapdoor_identity_other_curves(ctx, pkg, S, n_constraints, n_pu
     with pytest.raises(pkg.DvnError):
         ctx._chk(getattr(ctx.L, f"dvn_{S.cname}_groth16_setup")(ctx.h, cs_bn.h, 9, __import__("ctypes").byref(__import__("ctypes").c_void_p())))
     cs_bn.free(); key.free(); cs.free()
+
+
+@pytest.mark.gpu
+def test_imported_key_on_other_curves(ctx, pkg, S):
+    """The gnark-key path (pk_import + prove_solved) on the voteverifier / aggregator / BLS12-381 curves: a key
+    exported from the Setup mirror and imported again proves from the solver's (w, a, b, c) to the same proof and to the trapdoor
+    identity."""
+    from oracle import curves_py as cp
+    n_constraints, n_public = 700, 3
+    cs = pkg.R1CS(3, n_constraints, n_public, curve=S.cname)
+    ocs = cp.SyntheticR1CSOn(S, n_constraints, n_public, 3)
+    key = pkg.Groth16Key(ctx, cs, 9)
+    ik = pkg.ImportedKey(ctx, key.log_n, cs.n_wires, key.export_arrays(cs.n_wires, cs.n_public), curve=S.cname)
+    w = cs.witness()
+    ev = lambda rows: np.array([S.fr_to_limbs(sum(c * ocs.witness[i] for i, c in row) % S.r) for row in rows], dtype=np.uint64)
+    r, s = S.fr_at(1, 0), S.fr_at(1, 1)
+    rl, sl = np.array(S.fr_to_limbs(r), dtype=np.uint64), np.array(S.fr_to_limbs(s), dtype=np.uint64)
+    got = ik.prove_solved(w, ev(ocs.A), ev(ocs.B), ev(ocs.C), rl, sl)
+    want = key.prove(w, rl, sl)
+    closed = cp.groth16_expected_from_trapdoor_on(ocs, 9, r, s)
+    for k in ("Ar", "Bs", "Krs"):
+        assert (got[k] == want[k]).all(), k
+    assert list(got["Ar"]) == S.g1_to_limbs(closed["Ar"]) and list(got["Krs"]) == S.g1_to_limbs(closed["Krs"])
+    ik.free(); key.free(); cs.free()
