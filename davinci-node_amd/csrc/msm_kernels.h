@@ -549,6 +549,10 @@ __global__ __launch_bounds__(128, AccMinBlocks<Cv>::value) void k_accumulate(con
         st_xyzz<Cv>(Cv::acc_normalize(acc), dst);
         (void)end_x;
     };
+#ifndef DVN_ACC_PREFETCH
+#define DVN_ACC_PREFETCH 1      // measured (bench, 2^22): 0 -> 780, 1 -> 787-791, 2 (+ 3-wave bound: 168 VGPRs, 32 B scratch) -> 775-790 Mscalar/s
+#endif
+#if DVN_ACC_PREFETCH == 0
     for (u32 x = pos0; x < pos1; ++x) {
         if (x == b_end) {                       // bucket b is exhausted: store its run, move to the next non-empty bucket
             flush(x);
@@ -561,6 +565,43 @@ __global__ __launch_bounds__(128, AccMinBlocks<Cv>::value) void k_accumulate(con
         if (e & SIGN_BIT) p = Cv::neg(p);
         acc = Cv::acc_add_mixed(acc, p);
     }
+#elif DVN_ACC_PREFETCH == 1
+    // the sorted entry of iteration x + 1 is fetched before the addition of iteration x: the point gather of the next iteration
+    // no longer waits for its index
+    u32 e = src[pos0];
+    for (u32 x = pos0; x < pos1; ++x) {
+        if (x == b_end) {
+            flush(x);
+            acc = Cv::infinity();
+            do { ++b; } while (cnt[b] == 0);
+            b_start = off[b]; b_end = b_start + cnt[b];
+        }
+        const u32 e_next = src[x + 1 < pos1 ? x + 1 : x];
+        A p = ld_affine<Cv>(points + (pts_off + (size_t)(e & ~SIGN_BIT)) * Cv::AW);
+        if (e & SIGN_BIT) p = Cv::neg(p);
+        acc = Cv::acc_add_mixed(acc, p);
+        e = e_next;
+    }
+#else
+    // ... and the next point itself (raw words) is in flight during the addition
+    u32 e = src[pos0];
+    u32 raw[Cv::AW];
+    load_words16(points + (pts_off + (size_t)(e & ~SIGN_BIT)) * Cv::AW, raw, Cv::AW);
+    for (u32 x = pos0; x < pos1; ++x) {
+        if (x == b_end) {
+            flush(x);
+            acc = Cv::infinity();
+            do { ++b; } while (cnt[b] == 0);
+            b_start = off[b]; b_end = b_start + cnt[b];
+        }
+        A p = Cv::load_affine_internal(raw);
+        if (e & SIGN_BIT) p = Cv::neg(p);
+        const u32 e_next = src[x + 1 < pos1 ? x + 1 : x];
+        load_words16(points + (pts_off + (size_t)(e_next & ~SIGN_BIT)) * Cv::AW, raw, Cv::AW);
+        acc = Cv::acc_add_mixed(acc, p);
+        e = e_next;
+    }
+#endif
     flush(pos1);
 }
 
