@@ -280,3 +280,82 @@ def test_gpu_kzg_concurrent_callers(dev, ctx, pkg, K, ts, blobs, orc):
         t.join()
     pts.free()
     assert not errs, errs
+
+
+# ---------------------------------------------------------------- part 3: proofs VERIFIED by the setup's G2 side (pairing)
+@pytest.fixture(scope="module")
+def BP():
+    from oracle import bls12381_pairing_py
+    return bls12381_pairing_py
+
+
+@pytest.fixture(scope="module")
+def g2pts(BP):
+    lines = open(os.path.join(GOLDEN, "kzg_trusted_setup.txt")).read().split()
+    raw = [bytes.fromhex(h) for h in lines[2 + 4096:2 + 4096 + 65]]
+    return {0: BP.g2_decompress(raw[0]), 1: BP.g2_decompress(raw[1]), 64: BP.g2_decompress(raw[64])}
+
+
+def kzg_verify(K, BP, g2pts, commitment48, z, y, proof48):
+    """EIP-4844 verify_kzg_proof_impl: e(pi, [tau]_2 - [z]_2) * e(-(C - [y]_1), [1]_2) == 1, G2 points from the reference's file."""
+    c, pi = K.g1_decompress(commitment48), K.g1_decompress(proof48)
+    lhs2 = BP.g2_add(g2pts[1], BP.g2_neg(BP.g2_mul(g2pts[0], z)))
+    cy = K.g1_add(c, K.g1_mul(K.G1_GEN, (K.R - y) % K.R))
+    neg = None if cy is None else (cy[0], (-cy[1]) % K.P)
+    return BP.pairing_check([(pi, lhs2), (neg, g2pts[0])])
+
+
+def cell_verify(K, BP, ts, g2pts, commitment48, coeffs, k, proof48):
+    """EIP-7594 cell proof equation for one cell: e(pi_k, [tau^64]_2 - [c_k]_2) * e(-(C - [I_k(tau)]_1), [1]_2) == 1 with
+    I_k = f mod (X^64 - c_k) taken straight from the coefficients (no quotient involved)."""
+    ck = pow(K.cell_coset_shift(k), 64, K.R)
+    ik = [sum(coeffs[j + 64 * t] * pow(ck, t, K.R) for t in range(64)) % K.R for j in range(64)]
+    c, pi = K.g1_decompress(commitment48), K.g1_decompress(proof48)
+    ci = K.g1_add(c, K.g1_msm(ts.g1_monomial[:64], [(K.R - v) % K.R for v in ik], c=4))
+    neg = None if ci is None else (ci[0], (-ci[1]) % K.P)
+    lhs2 = BP.g2_add(g2pts[64], BP.g2_neg(BP.g2_mul(g2pts[0], ck)))
+    return BP.pairing_check([(pi, lhs2), (neg, g2pts[0])])
+
+
+def test_pairing_pinned_by_the_two_sides_of_the_setup(K, BP, ts, g2pts):
+    """The file's G1 and G2 powers share tau: e([tau^j]_1, [1]_2) == e([1]_1, [tau^j]_2) for j = 1, 64 -- pins the pairing (and
+    both decompressions) on reference data; plus bilinearity, order and non-degeneracy."""
+    g1, g2 = K.G1_GEN, g2pts[0]
+    e = BP.pairing(g2, g1)
+    assert not (e == BP.F12.one()) and e ** K.R == BP.F12.one()
+    assert BP.pairing(BP.g2_mul(g2, 5), K.g1_mul(g1, 3)) == e ** 15
+    ng1 = (g1[0], (-g1[1]) % K.P)
+    for j in (1, 64):
+        assert BP.pairing_check([(ts.g1_monomial[j], g2), (ng1, g2pts[j])])
+    assert not BP.pairing_check([(ts.g1_monomial[2], g2), (ng1, g2pts[1])])
+
+
+def test_oracle_proofs_verify_under_the_setup(K, BP, ts, g2pts, blobs):
+    blob = blobs[0]
+    c = K.blob_to_commitment(ts, blob)
+    for z in (987654321, K.domain_brp(4096)[77]):
+        proof, y = K.compute_proof(ts, blob, z)
+        assert kzg_verify(K, BP, g2pts, c, z, y, proof)
+        assert not kzg_verify(K, BP, g2pts, c, z, (y + 1) % K.R, proof)
+    coeffs = K.blob_coefficients(blob)
+    assert cell_verify(K, BP, ts, g2pts, c, coeffs, 9, K.compute_cell_proof(ts, blob, 9, coeffs))
+    assert not cell_verify(K, BP, ts, g2pts, c, coeffs, 10, K.compute_cell_proof(ts, blob, 9, coeffs))
+
+
+@pytest.mark.gpu
+def test_gpu_proofs_verify_under_the_setup(dev, K, BP, ts, g2pts, blobs):
+    """The HIP path's commitment / opening / blob / cell proofs accepted by the pairing equations over the reference's own G2
+    points -- no oracle arithmetic between the device output and the check except the verifier's."""
+    blob = blobs[1]
+    c = dev.compute_commitment(blob)
+    for z in (0xDEADBEEF12345, K.domain_brp(4096)[4000]):
+        proof, y = dev.compute_proof(blob, z)
+        assert kzg_verify(K, BP, g2pts, c, z, y, proof)
+    bp_ = dev.compute_blob_proof(blob, c)
+    zc = K.compute_challenge(blob, c)
+    assert kzg_verify(K, BP, g2pts, c, zc, dev.evaluate_barycentric(blob, zc), bp_)
+    cells = dev.compute_cell_proofs(blob)
+    coeffs = K.blob_coefficients(blob)
+    for k in (0, 37, 127):
+        assert cell_verify(K, BP, ts, g2pts, c, coeffs, k, cells[k])
+    assert not cell_verify(K, BP, ts, g2pts, c, coeffs, 1, cells[2])
