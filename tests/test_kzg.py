@@ -359,3 +359,25 @@ def test_gpu_proofs_verify_under_the_setup(dev, K, BP, ts, g2pts, blobs):
     for k in (0, 37, 127):
         assert cell_verify(K, BP, ts, g2pts, c, coeffs, k, cells[k])
     assert not cell_verify(K, BP, ts, g2pts, c, coeffs, 1, cells[2])
+
+
+@pytest.mark.gpu
+def test_gpu_bls12381_g2_msm_pinned_by_the_setup(ctx, pkg, K, BP, ts):
+    """The device's BLS12-381 G2 MSM over the file's 65 G2 powers: [p(tau)]_2 for a random degree-64 p must pair like the
+    [p(tau)]_1 the G1 monomial basis gives -- e([p(tau)]_1, [1]_2) == e([1]_1, [p(tau)]_2)."""
+    from oracle import curves_py
+    S = curves_py.BLS12_381
+    lines = open(os.path.join(GOLDEN, "kzg_trusted_setup.txt")).read().split()
+    g2 = [BP.g2_decompress(bytes.fromhex(h)) for h in lines[2 + 4096:2 + 4096 + 65]]
+    rng = random.Random(21)
+    coef = [rng.randrange(K.R) for _ in range(65)]
+    bls = pkg.Bls12381(ctx)
+    pts = bls.upload_g2(np.array([S.g2_to_limbs(p) for p in g2], dtype=np.uint64))
+    out = bls.msm_g2(pts, np.array([S.fr_to_limbs(c) for c in coef], dtype=np.uint64))
+    assert out[24:36].any()                                                   # Z != 0
+    x = (S.fp_from_mont(int(sum(int(out[i]) << (64 * i) for i in range(6)))), S.fp_from_mont(int(sum(int(out[6 + i]) << (64 * i) for i in range(6)))))
+    y = (S.fp_from_mont(int(sum(int(out[12 + i]) << (64 * i) for i in range(6)))), S.fp_from_mont(int(sum(int(out[18 + i]) << (64 * i) for i in range(6)))))
+    p1 = K.g1_msm(ts.g1_monomial[:65], coef, c=4)
+    ng1 = (K.G1_GEN[0], (-K.G1_GEN[1]) % K.P)
+    assert BP.pairing_check([(p1, g2[0]), (ng1, (x, y))])
+    pts.free()
