@@ -125,3 +125,37 @@ def test_imported_key_on_other_curves(ctx, pkg, S):
         assert (got[k] == want[k]).all(), k
     assert list(got["Ar"]) == S.g1_to_limbs(closed["Ar"]) and list(got["Krs"]) == S.g1_to_limbs(closed["Krs"])
     ik.free(); key.free(); cs.free()
+
+
+@pytest.mark.gpu
+def test_bls12381_device_proof_passes_groth16_verify(ctx, pkg):
+    """Prove -> verify on BLS12-381 with the library's own verifying key: e(A, B) == e(alpha, beta) e(vk_x, gamma) e(C, delta), over
+    the big-int pairing that tests/test_kzg.py pins on the reference's trusted setup."""
+    from oracle import curves_py as cp, bls12381_pairing_py as BP, kzg_py as K
+    S = cp.BLS12_381
+    n_constraints, n_public = 400, 4
+    cs = pkg.R1CS(3, n_constraints, n_public, curve="bls12381")
+    key = pkg.Groth16Key(ctx, cs, 9)
+    vk = key.verifying_key(n_public)
+    def fp(words):
+        return S.fp_from_mont(int(sum(int(w) << (64 * i) for i, w in enumerate(words))))
+    def g1(l):
+        l = [int(v) for v in l]
+        return None if not any(l) else (fp(l[0:6]), fp(l[6:12]))
+    def g2(l):
+        l = [int(v) for v in l]
+        return None if not any(l) else ((fp(l[0:6]), fp(l[6:12])), (fp(l[12:18]), fp(l[18:24])))
+    w = cs.witness()
+    r, s = S.fr_at(2, 0), S.fr_at(2, 1)
+    proof = key.prove(w, np.array(S.fr_to_limbs(r), dtype=np.uint64), np.array(S.fr_to_limbs(s), dtype=np.uint64))
+    inputs = [S.fr_from_limbs(x) for x in w[1:n_public]]
+    acc = g1(vk["ic"][0])
+    for v, row in zip(inputs, vk["ic"][1:]):
+        acc = K.g1_add(acc, K.g1_mul(g1(row), v))
+    neg = lambda p: (p[0], (-p[1]) % K.P)
+    a, b, c = g1(proof["Ar"]), g2(proof["Bs"]), g1(proof["Krs"])
+    ok = BP.pairing_check([(a, b), (neg(c), g2(vk["delta"])), (neg(g1(vk["alpha"])), g2(vk["beta"])), (neg(acc), g2(vk["gamma"]))])
+    assert ok
+    acc_bad = K.g1_add(acc, K.G1_GEN)
+    assert not BP.pairing_check([(a, b), (neg(c), g2(vk["delta"])), (neg(g1(vk["alpha"])), g2(vk["beta"])), (neg(acc_bad), g2(vk["gamma"]))])
+    key.free(); cs.free()
