@@ -148,6 +148,13 @@ def test_gpu_setup_decompression_matches_reference_bases(dev, ts, K, ctx, pkg):
     # f = X^5 in evaluation form -> [tau^5]
     blob5 = b"".join(pow(w, 5, K.R).to_bytes(32, "big") for w in K.domain_brp(4096))
     assert dev.compute_commitment(blob5) == ts.g1_monomial_bytes[5]
+    # every element r - 1 (all 4096 entries of every table row land in ONE bucket: the heavy-bucket path): -[1]G1
+    neg_g = (K.G1_GEN[0], K.P - K.G1_GEN[1])
+    assert dev.compute_commitment((K.R - 1).to_bytes(32, "big") * 4096) == K.g1_compress(neg_g)
+    # the constant polynomial has zero quotients everywhere: all 128 cell proofs and the opening proof are the point at infinity
+    inf = bytes([0xC0]) + bytes(47)
+    assert dev.compute_cell_proofs(ones * 4096) == [inf] * 128
+    assert dev.compute_proof(ones * 4096, 5) == (inf, 1)
 
 
 @pytest.mark.gpu
