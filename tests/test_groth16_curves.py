@@ -128,13 +128,23 @@ def test_imported_key_on_other_curves(ctx, pkg, S):
 
 
 @pytest.mark.gpu
-def test_bls12381_device_proof_passes_groth16_verify(ctx, pkg):
-    """Prove -> verify on BLS12-381 with the library's own verifying key: e(A, B) == e(alpha, beta) e(vk_x, gamma) e(C, delta), over
-    the big-int pairing that tests/test_kzg.py pins on the reference's trusted setup."""
-    from oracle import curves_py as cp, bls12381_pairing_py as BP, kzg_py as K
-    S = cp.BLS12_381
+@pytest.mark.parametrize("curve", ["bls12381", "bls12377"])
+def test_device_proof_passes_groth16_verify(ctx, pkg, curve):
+    """Prove -> verify on BLS12-381 and on the voteverifier curve BLS12-377 with the library's own verifying key:
+    e(A, B) == e(alpha, beta) e(vk_x, gamma) e(C, delta) over big-int pairings (the BLS12-381 one is pinned on the reference's
+    trusted setup in tests/test_kzg.py, the BLS12-377 one by bilinearity / order / non-degeneracy here)."""
+    from oracle import curves_py as cp
+    if curve == "bls12381":
+        from oracle import bls12381_pairing_py as BP
+        S = cp.BLS12_381
+    else:
+        from oracle import bls12377_pairing_py as BP
+        S = cp.BLS12_377
+        e = BP.pairing(S.g2_gen, S.g1_gen)
+        assert not (e == BP.F12.one()) and e ** S.r == BP.F12.one()
+        assert BP.pairing(S.g2_mul(S.g2_gen, 5), S.g1_mul(S.g1_gen, 3)) == e ** 15
     n_constraints, n_public = 400, 4
-    cs = pkg.R1CS(3, n_constraints, n_public, curve="bls12381")
+    cs = pkg.R1CS(3, n_constraints, n_public, curve=curve)
     key = pkg.Groth16Key(ctx, cs, 9)
     vk = key.verifying_key(n_public)
     def fp(words):
@@ -151,11 +161,10 @@ def test_bls12381_device_proof_passes_groth16_verify(ctx, pkg):
     inputs = [S.fr_from_limbs(x) for x in w[1:n_public]]
     acc = g1(vk["ic"][0])
     for v, row in zip(inputs, vk["ic"][1:]):
-        acc = K.g1_add(acc, K.g1_mul(g1(row), v))
-    neg = lambda p: (p[0], (-p[1]) % K.P)
+        acc = S.g1_add(acc, S.g1_mul(g1(row), v))
+    neg = lambda p: (p[0], (-p[1]) % S.p)
     a, b, c = g1(proof["Ar"]), g2(proof["Bs"]), g1(proof["Krs"])
-    ok = BP.pairing_check([(a, b), (neg(c), g2(vk["delta"])), (neg(g1(vk["alpha"])), g2(vk["beta"])), (neg(acc), g2(vk["gamma"]))])
-    assert ok
-    acc_bad = K.g1_add(acc, K.G1_GEN)
+    assert BP.pairing_check([(a, b), (neg(c), g2(vk["delta"])), (neg(g1(vk["alpha"])), g2(vk["beta"])), (neg(acc), g2(vk["gamma"]))])
+    acc_bad = S.g1_add(acc, S.g1_gen)
     assert not BP.pairing_check([(a, b), (neg(c), g2(vk["delta"])), (neg(g1(vk["alpha"])), g2(vk["beta"])), (neg(acc_bad), g2(vk["gamma"]))])
     key.free(); cs.free()
