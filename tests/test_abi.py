@@ -52,3 +52,15 @@ def test_null_arguments_rejected(pkg):
     assert L.dvn_init(None, 0, None) == -1
     assert L.dvn_msm_plan(16, None, None) == -1
     assert L.dvn_malloc(None, 16, None) == -1
+
+
+def test_header_is_plain_c():
+    """The drop-in boundary is a C ABI (cgo consumes the header): it must compile as C99 with no C++ or torch types."""
+    import os
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "hdr.c")
+        open(src, "w").write('#include "dvn_prover.h"\nint main(void) { return 0; }\n')
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), "-fsyntax-only", src])
