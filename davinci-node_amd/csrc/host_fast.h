@@ -157,6 +157,14 @@ template <class O> struct Group {
         }
         return acc;
     }
+    static inline X mul_scalar_n(const X& p, const uint32_t* k, uint32_t nwords) {
+        X acc = infinity();
+        for (int b = (int)nwords * 32 - 1; b >= 0; --b) {
+            acc = dbl(acc);
+            if ((k[b >> 5] >> (b & 31)) & 1) acc = add(acc, p);
+        }
+        return acc;
+    }
     // device affine image (internal form, 2 coordinates; all zero = infinity) -> X with ZZ = ZZZ = 1
     static inline X load_device_affine(const uint32_t* w) {
         bool z = true;
@@ -178,5 +186,112 @@ template <class O> struct Group {
 };
 typedef Group<OpsFq> HG1;
 typedef Group<OpsFq2> HG2;
+
+// ---- the same finishing arithmetic for the wider fields (BLS12-377 / BLS12-381: 6 limbs, BW6-761: 12 limbs), Montgomery
+// R = 2^(64 NW) = gnark's own form.  Cfg is the device field config (29-bit limb tables): the constants are derived from it once.
+template <int NW> struct FqN { u64 l[NW]; };
+template <class Cfg, int NW> struct OpsFqN {
+    typedef FqN<NW> F;
+    struct K { u64 p[NW]; u64 n0; F one, conv; };
+    static inline bool geq(const u64* a, const u64* b) { for (int i = NW - 1; i >= 0; --i) { if (a[i] != b[i]) return a[i] > b[i]; } return true; }
+    static inline void sub_in(u64* a, const u64* b) { u128 br = 0; for (int i = 0; i < NW; ++i) { u128 d = (u128)a[i] - b[i] - br; a[i] = (u64)d; br = (d >> 64) & 1; } }
+    static const K& k() {
+        static const K c = []() {
+            K q; memset(&q, 0, sizeof(q));
+            for (int i = 0; i < Cfg::NL; ++i) {                  // modulus from the 29-bit limb table
+                const int bit = 29 * i, w = bit >> 6, sh = bit & 63;
+                const u64 v = Cfg::p(i);
+                if (w < NW) q.p[w] |= v << sh;
+                if (sh + 29 > 64 && w + 1 < NW) q.p[w + 1] |= v >> (64 - sh);
+            }
+            u64 inv = 1;
+            for (int i = 0; i < 6; ++i) inv *= 2 - q.p[0] * inv;
+            q.n0 = (u64)0 - inv;
+            u64 x[NW]; memset(x, 0, sizeof(x)); x[0] = 1;       // 2^(64 NW) mod p by doubling
+            for (int i = 0; i < 64 * NW; ++i) {
+                const u64 hi = x[NW - 1] >> 63;
+                for (int j = NW - 1; j > 0; --j) x[j] = (x[j] << 1) | (x[j - 1] >> 63);
+                x[0] <<= 1;
+                if (hi || geq(x, q.p)) sub_in(x, q.p);
+            }
+            memcpy(q.one.l, x, sizeof(x));
+            // device word = x * 2^(29 NL); Montgomery product with the integer 2^(2*64 NW - 29 NL) turns it into x * 2^(64 NW)
+            const int e = 2 * 64 * NW - 29 * Cfg::NL;
+            q.conv.l[e >> 6] = 1ull << (e & 63);
+            return q;
+        }();
+        return c;
+    }
+    static inline F add(const F& a, const F& b) {
+        const K& c = k(); F r; u128 cy = 0;
+        for (int i = 0; i < NW; ++i) { cy += (u128)a.l[i] + b.l[i]; r.l[i] = (u64)cy; cy >>= 64; }
+        if (cy || geq(r.l, c.p)) sub_in(r.l, c.p);
+        return r;
+    }
+    static inline F sub(const F& a, const F& b) {
+        const K& c = k(); F r; u128 br = 0;
+        for (int i = 0; i < NW; ++i) { u128 d = (u128)a.l[i] - b.l[i] - br; r.l[i] = (u64)d; br = (d >> 64) & 1; }
+        if (br) { u128 cy = 0; for (int i = 0; i < NW; ++i) { cy += (u128)r.l[i] + c.p[i]; r.l[i] = (u64)cy; cy >>= 64; } }
+        return r;
+    }
+    static inline F mul(const F& a, const F& b) {          // CIOS
+        const K& c = k();
+        u64 t[NW + 2]; memset(t, 0, sizeof(t));
+        for (int i = 0; i < NW; ++i) {
+            u128 cy = 0;
+            for (int j = 0; j < NW; ++j) { cy += (u128)a.l[j] * b.l[i] + t[j]; t[j] = (u64)cy; cy >>= 64; }
+            cy += t[NW]; t[NW] = (u64)cy; t[NW + 1] = (u64)(cy >> 64);
+            const u64 m = t[0] * c.n0;
+            cy = (u128)m * c.p[0] + t[0]; cy >>= 64;
+            for (int j = 1; j < NW; ++j) { cy += (u128)m * c.p[j] + t[j]; t[j - 1] = (u64)cy; cy >>= 64; }
+            cy += t[NW]; t[NW - 1] = (u64)cy; t[NW] = t[NW + 1] + (u64)(cy >> 64);
+        }
+        if (t[NW] || geq(t, c.p)) sub_in(t, c.p);
+        F r; memcpy(r.l, t, sizeof(r.l)); return r;
+    }
+    static inline F sqr(const F& a) { return mul(a, a); }
+    static inline F zero() { F r; memset(&r, 0, sizeof(r)); return r; }
+    static inline F one() { return k().one; }
+    static inline bool is_zero(const F& a) { u64 z = 0; for (int i = 0; i < NW; ++i) z |= a.l[i]; return z == 0; }
+    static inline F neg(const F& a) { return is_zero(a) ? a : sub(zero(), a); }
+    static inline F inv(const F& a) {                       // a^(p-2)
+        const K& c = k();
+        u64 e[NW]; memcpy(e, c.p, sizeof(e)); e[0] -= 2;
+        F acc = c.one;
+        for (int i = 64 * NW - 1; i >= 0; --i) { acc = mul(acc, acc); if ((e[i >> 6] >> (i & 63)) & 1) acc = mul(acc, a); }
+        return acc;
+    }
+    static inline F from_device(const uint32_t* w) { F v; memcpy(v.l, w, sizeof(v.l)); return mul(v, k().conv); }
+    static inline void store(const F& a, uint64_t* o) { memcpy(o, a.l, sizeof(a.l)); }
+    static const int WORDS = 2 * NW, U64S = NW;
+};
+// quadratic extension Fq[u]/(u^2 + BETA) over it (BLS12-377: BETA = 5, BLS12-381: BETA = 1)
+template <class Cfg, int NW, int BETA> struct OpsFq2N {
+    typedef OpsFqN<Cfg, NW> B;
+    struct F { typename B::F a0, a1; };
+    static inline typename B::F mul_beta(const typename B::F& x) {
+        typename B::F r = x;
+        for (int i = 1; i < BETA; ++i) r = B::add(r, x);
+        return r;
+    }
+    static inline F add(const F& a, const F& b) { return F{B::add(a.a0, b.a0), B::add(a.a1, b.a1)}; }
+    static inline F sub(const F& a, const F& b) { return F{B::sub(a.a0, b.a0), B::sub(a.a1, b.a1)}; }
+    static inline F mul(const F& a, const F& b) {
+        const typename B::F t0 = B::mul(a.a0, b.a0), t1 = B::mul(a.a1, b.a1);
+        const typename B::F m = B::mul(B::add(a.a0, a.a1), B::add(b.a0, b.a1));
+        return F{B::sub(t0, mul_beta(t1)), B::sub(B::sub(m, t0), t1)};
+    }
+    static inline F sqr(const F& a) { return mul(a, a); }
+    static inline F inv(const F& a) {                       // (a0 - a1 u) / (a0^2 + BETA a1^2)
+        const typename B::F d = B::inv(B::add(B::mul(a.a0, a.a0), mul_beta(B::mul(a.a1, a.a1))));
+        return F{B::mul(a.a0, d), B::neg(B::mul(a.a1, d))};
+    }
+    static inline F zero() { return F{B::zero(), B::zero()}; }
+    static inline F one() { return F{B::one(), B::zero()}; }
+    static inline bool is_zero(const F& a) { return B::is_zero(a.a0) && B::is_zero(a.a1); }
+    static inline F from_device(const uint32_t* w) { return F{B::from_device(w), B::from_device(w + 2 * NW)}; }
+    static inline void store(const F& a, uint64_t* o) { B::store(a.a0, o); B::store(a.a1, o + NW); }
+    static const int WORDS = 4 * NW, U64S = 2 * NW;
+};
 
 }  // namespace dvn_host

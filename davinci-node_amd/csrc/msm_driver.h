@@ -537,6 +537,13 @@ template <class Cv> struct SlowHostG {
 template <class Cv> struct FastHost { typedef SlowHostG<Cv> G; };
 template <> struct FastHost<G1> { typedef dvn_host::HG1 G; };
 template <> struct FastHost<G2> { typedef dvn_host::HG2 G; };
+#ifndef DVN_SLOW_HOST            // -DDVN_SLOW_HOST: the device headers compiled for the host everywhere but BN254 (A/B checks)
+template <> struct FastHost<G1_377> { typedef dvn_host::Group<dvn_host::OpsFqN<Fp377Cfg, 6>> G; };
+template <> struct FastHost<G2_377> { typedef dvn_host::Group<dvn_host::OpsFq2N<Fp377Cfg, 6, 5>> G; };
+template <> struct FastHost<G1_381> { typedef dvn_host::Group<dvn_host::OpsFqN<Fp381Cfg, 6>> G; };
+template <> struct FastHost<G2_381> { typedef dvn_host::Group<dvn_host::OpsFq2N<Fp381Cfg, 6, 1>> G; };
+template <> struct FastHost<G_761> { typedef dvn_host::Group<dvn_host::OpsFqN<Fp761Cfg, 12>> G; };
+#endif
 
 // ---- lanes: submit (enqueue on a free lane) / wait --------------------------------------------------------------
 static inline int32_t lane_acquire(dvn_ctx* ctx, MsmLane** out) {
