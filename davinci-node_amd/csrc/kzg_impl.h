@@ -379,85 +379,22 @@ static int32_t kzg_load_blob(dvn_ctx* ctx, const dvn_kzg_setup* s, const uint8_t
     if (herr) return fail(DVN_ERR_INVALID_ARG, "blob element is not a canonical field element");
     return DVN_OK;
 }
-// ---- host finishing of ONE result point: 6 x 64-bit limb Montgomery arithmetic over Fp381 (a 381-bit Fermat inversion is ~25 us
-// here against 0.6 ms for one GPU lane: a single commitment / opening proof is normalised and compressed on the host, the 128 cell
-// proofs -- 128 independent inversions -- on the device)
-namespace kzg_host {
-typedef unsigned __int128 u128;
-struct F { u64 l[6]; };
-struct Consts { u64 p[6]; u64 n0; F r2, one; };
-static inline bool geq(const u64* a, const u64* b) { for (int i = 5; i >= 0; --i) { if (a[i] != b[i]) return a[i] > b[i]; } return true; }
-static inline void sub_in(u64* a, const u64* b) { u128 br = 0; for (int i = 0; i < 6; ++i) { u128 d = (u128)a[i] - b[i] - br; a[i] = (u64)d; br = (d >> 64) & 1; } }
-static inline F mont_mul(const Consts& c, const F& a, const F& b) {           // CIOS: a b / 2^384 mod p
-    u64 t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < 6; ++i) {
-        u128 cy = 0;
-        for (int j = 0; j < 6; ++j) { cy += (u128)a.l[j] * b.l[i] + t[j]; t[j] = (u64)cy; cy >>= 64; }
-        cy += t[6]; t[6] = (u64)cy; t[7] = (u64)(cy >> 64);
-        const u64 m = t[0] * c.n0;
-        cy = (u128)m * c.p[0] + t[0]; cy >>= 64;
-        for (int j = 1; j < 6; ++j) { cy += (u128)m * c.p[j] + t[j]; t[j - 1] = (u64)cy; cy >>= 64; }
-        cy += t[6]; t[5] = (u64)cy; t[6] = t[7] + (u64)(cy >> 64);
-    }
-    if (t[6] || geq(t, c.p)) sub_in(t, c.p);
-    F r; memcpy(r.l, t, 48); return r;
-}
-static const Consts& consts() {
-    static const Consts c = []() {
-        Consts k; memset(&k, 0, sizeof(k));
-        // p from the 29-bit limb table of the device field
-        for (int i = 0; i < Fp381Cfg::NL; ++i) {
-            const int bit = LB * i, w = bit >> 6, sh = bit & 63;
-            const u64 v = Fp381Cfg::p(i);
-            k.p[w] |= v << sh;
-            if (sh + LB > 64 && w + 1 < 6) k.p[w + 1] |= v >> (64 - sh);
-        }
-        u64 inv = 1;                                                             // p^-1 mod 2^64 by Newton, then negate
-        for (int i = 0; i < 6; ++i) inv *= 2 - k.p[0] * inv;
-        k.n0 = (u64)0 - inv;
-        u64 x[6] = {1, 0, 0, 0, 0, 0};                                            // 2^768 mod p by doubling
-        for (int i = 0; i < 768; ++i) {
-            u64 hi = x[5] >> 63;
-            for (int j = 5; j > 0; --j) x[j] = (x[j] << 1) | (x[j - 1] >> 63);
-            x[0] <<= 1;
-            if (hi || geq(x, k.p)) sub_in(x, k.p);
-            if (i == 383) memcpy(k.one.l, x, 48);                                 // 2^384 mod p = Montgomery one
-        }
-        memcpy(k.r2.l, x, 48);
-        return k;
-    }();
-    return c;
-}
-static inline F inv(const Consts& c, const F& a) {                               // a^(p-2), Montgomery domain
-    u64 e[6]; memcpy(e, c.p, 48); e[0] -= 2;
-    F acc = c.one;
-    for (int i = 383; i >= 0; --i) { acc = mont_mul(c, acc, acc); if ((e[i >> 6] >> (i & 63)) & 1) acc = mont_mul(c, acc, a); }
-    return acc;
-}
-// internal xyzz image (4 x 12 u32 words; every coordinate carries the same factor 2^406) -> 48 compressed bytes
-static void compress_xyzz(const u32* w, uint8_t out[48]) {
-    const Consts& c = consts();
-    bool z = true;
-    for (int i = 0; i < 12; ++i) z = z && w[24 + i] == 0;
-    if (z) { memset(out, 0, 48); out[0] = 0xC0; return; }
-    F X, Y, ZZ, ZZZ;
-    memcpy(X.l, w, 48); memcpy(Y.l, w + 12, 48); memcpy(ZZ.l, w + 24, 48); memcpy(ZZZ.l, w + 36, 48);
-    auto to_m = [&](const F& v) { return mont_mul(c, v, c.r2); };
-    // every coordinate image carries the same factor 2^406, so only RATIOS of images are meaningful: x = X / ZZ, y = Y / ZZZ
-    // with one inversion of ZZ * ZZZ
-    const F mX = to_m(X), mY = to_m(Y), mZZ = to_m(ZZ), mZZZ = to_m(ZZZ);
-    const F ib = inv(c, mont_mul(c, mZZ, mZZZ));
-    F one_int; memset(&one_int, 0, sizeof(one_int)); one_int.l[0] = 1;
-    const F x = mont_mul(c, mont_mul(c, mX, mont_mul(c, ib, mZZZ)), one_int);      // canonical integers
-    const F y = mont_mul(c, mont_mul(c, mY, mont_mul(c, ib, mZZ)), one_int);
+// ---- host finishing of ONE result point (host_fast.h, 6 x 64-bit limbs): a 381-bit Fermat inversion is ~25 us here against 0.6 ms
+// for one GPU lane, so a single commitment / opening proof is normalised and compressed on the host, the 128 cell proofs -- 128
+// independent inversions -- on the device.  w: internal xyzz image (4 x 12 u32 words) -> 48 compressed bytes.
+static void kzg_compress_xyzz_host(const u32* w, uint8_t out[48]) {
+    typedef dvn_host::OpsFqN<Fp381Cfg, 6> O;
+    typedef dvn_host::Group<O> HG;
+    const HG::X pnt = HG::load_device(w);
+    if (HG::is_inf(pnt)) { memset(out, 0, 48); out[0] = 0xC0; return; }
+    const HG::X a = HG::normalize(pnt);
+    O::F one_int = O::zero(); one_int.l[0] = 1;
+    const O::F x = O::mul(a.x, one_int), y = O::mul(a.y, one_int);                 // Montgomery -> canonical integers
     for (int i = 0; i < 6; ++i) for (int k = 0; k < 8; ++k) out[8 * (5 - i) + (7 - k)] = (uint8_t)(x.l[i] >> (8 * k));
-    u64 y2[6]; u64 hi = y.l[5] >> 63;                                             // 2y > p ?
-    for (int j = 5; j > 0; --j) y2[j] = (y.l[j] << 1) | (y.l[j - 1] >> 63);
-    y2[0] = y.l[0] << 1;
-    const bool largest = hi || (geq(y2, c.p) && memcmp(y2, c.p, 48) != 0);
+    const O::F y2 = O::add(y, y);                                                    // 2y mod p = 2y - p iff 2y > p: odd then (p odd)
+    const bool largest = !O::is_zero(y) && (y2.l[0] & 1);
     out[0] |= 0x80 | (largest ? 0x20 : 0x00);
 }
-}  // namespace kzg_host
 
 // `batch` MSMs of n scalars each over pts[0, n) (expanded table `tab`, window c) -> `batch` compressed points in out48
 // (caller holds ctx->mu)
@@ -470,7 +407,7 @@ static int32_t kzg_commit(dvn_ctx* ctx, const dvn_kzg_setup* s, const dvn_points
         int32_t rc1 = lane_wait(ctx, *L);
         if (e1 != hipSuccess) { (void)hipGetLastError(); return fail(DVN_ERR_DEVICE, "result copy failed: %s", hipGetErrorString(e1)); }
         TRY(rc1);
-        kzg_host::compress_xyzz(h, out48);
+        kzg_compress_xyzz_host(h, out48);
         return DVN_OK;
     }
     uint8_t* d_out = s->d_bytes + (size_t)kzg::N * 40;                 // tail of the staging buffer (6 KiB needed)
