@@ -3,6 +3,7 @@
 // This library is a test seam only; it is never loaded by the product path.
 #include <cstring>
 #include "bn254_curve.h"
+#include "host_fast.h"
 using namespace dvn;
 
 template <class C> static void bin(const uint32_t* a, const uint32_t* b, uint32_t* r, int op) {
@@ -189,4 +190,31 @@ void hc761_acc_chain(const uint32_t* pts, const uint32_t* idx, size_t n, uint32_
     }
     G_761::affine_to_ext(G_761::to_affine(G_761::acc_normalize(acc)), out);
 }
+}
+
+
+// ---- the 64-bit-limb host finishing arithmetic (host_fast.h OpsFqN / OpsFq2N) of the wider fields ------------------------------
+// a, b, r: Montgomery images (R = 2^(64 NW)), NW uint64 each.  op: 0 mul, 1 add, 2 sub, 4 inv.  which: 0 BLS12-377 Fp, 1 BLS12-381 Fp,
+// 2 BW6-761 Fp.
+template <class O> static void hf_bin(const uint64_t* a, const uint64_t* b, uint64_t* r, int op) {
+    typename O::F x, y, z;
+    memcpy(x.l, a, sizeof(x.l)); memcpy(y.l, b, sizeof(y.l));
+    switch (op) { case 0: z = O::mul(x, y); break; case 1: z = O::add(x, y); break; case 2: z = O::sub(x, y); break; default: z = O::inv(x); break; }
+    memcpy(r, z.l, sizeof(z.l));
+}
+extern "C" void hc_hostfast_op(int which, const uint64_t* a, const uint64_t* b, uint64_t* r, int op) {
+    if (which == 0) hf_bin<dvn_host::OpsFqN<Fp377Cfg, 6>>(a, b, r, op);
+    else if (which == 1) hf_bin<dvn_host::OpsFqN<Fp381Cfg, 6>>(a, b, r, op);
+    else hf_bin<dvn_host::OpsFqN<Fp761Cfg, 12>>(a, b, r, op);
+}
+// device internal image (x * 2^(29 NL), packed little-endian words) -> Montgomery image x * 2^(64 NW)
+extern "C" void hc_hostfast_from_device(int which, const uint32_t* w, uint64_t* r) {
+    if (which == 0) { auto v = dvn_host::OpsFqN<Fp377Cfg, 6>::from_device(w); memcpy(r, v.l, sizeof(v.l)); }
+    else if (which == 1) { auto v = dvn_host::OpsFqN<Fp381Cfg, 6>::from_device(w); memcpy(r, v.l, sizeof(v.l)); }
+    else { auto v = dvn_host::OpsFqN<Fp761Cfg, 12>::from_device(w); memcpy(r, v.l, sizeof(v.l)); }
+}
+// Fp2 product over BLS12-377 (u^2 = -5) / BLS12-381 (u^2 = -1): a, b, r = 12 uint64 (a0 | a1)
+extern "C" void hc_hostfast_fp2_mul(int which, const uint64_t* a, const uint64_t* b, uint64_t* r, int inv) {
+    if (which == 0) { typedef dvn_host::OpsFq2N<Fp377Cfg, 6, 5> O; O::F x, y; memcpy(&x, a, 96); memcpy(&y, b, 96); O::F z = inv ? O::inv(x) : O::mul(x, y); memcpy(r, &z, 96); }
+    else { typedef dvn_host::OpsFq2N<Fp381Cfg, 6, 1> O; O::F x, y; memcpy(&x, a, 96); memcpy(&y, b, 96); O::F z = inv ? O::inv(x) : O::mul(x, y); memcpy(r, &z, 96); }
 }

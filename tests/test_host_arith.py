@@ -75,3 +75,44 @@ def test_naive_msm_through_device_group_law(hc, opy, orc):
     r2 = np.zeros(16, dtype=np.uint64)
     hc.hc_g2_msm_naive(p(pts2), p(k), C.c_size_t(5), p(r2))
     assert (r2 == orc.msm_g2(pts2, km[:5])).all()
+
+
+@pytest.mark.parametrize("which,name", [(0, "bls12377"), (1, "bls12381"), (2, "bw6761")])
+def test_hostfast_wide_fields(hc, which, name):
+    """The 64-bit-limb host finishing arithmetic of the wider curves (host_fast.h OpsFqN / OpsFq2N: window combine, blinding and
+    assembly of a proof, KZG result compression) against Python big ints."""
+    import random
+    from oracle import curves_py as cp
+    p_ = {0: cp.BLS12_377.p, 1: cp.BLS12_381.p, 2: cp.BW6_761.p}[which]
+    nw = 12 if which == 2 else 6
+    nl = 27 if which == 2 else 14
+    Rm = 1 << (64 * nw)
+    enc = lambda x: np.array([(x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(nw)], dtype=np.uint64)
+    dec = lambda a: sum(int(v) << (64 * i) for i, v in enumerate(a))
+    q = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint64))
+    rng = random.Random(which + 1)
+    vals = [(0, 0), (1, p_ - 1), (p_ - 1, p_ - 1)] + [(rng.randrange(p_), rng.randrange(p_)) for _ in range(200)]
+    r = np.zeros(nw, dtype=np.uint64)
+    for i, (a, b) in enumerate(vals):
+        am, bm = enc(a * Rm % p_), enc(b * Rm % p_)
+        for op, want in ((0, a * b % p_), (1, (a + b) % p_), (2, (a - b) % p_)):
+            hc.hc_hostfast_op(which, q(am), q(bm), q(r), op)
+            assert dec(r) == want * Rm % p_, (name, op, i)
+        if i < 8 and a:
+            hc.hc_hostfast_op(which, q(am), q(bm), q(r), 4)
+            assert dec(r) == pow(a, -1, p_) * Rm % p_
+        # device image x * 2^(29 NL) -> x * 2^(64 NW)
+        img = np.frombuffer((a * (1 << (29 * nl)) % p_).to_bytes(8 * nw, "little"), dtype=np.uint32).copy()
+        hc.hc_hostfast_from_device(which, img.ctypes.data_as(C.POINTER(C.c_uint32)), q(r))
+        assert dec(r) == a * Rm % p_
+    if which < 2:
+        beta = 5 if which == 0 else 1
+        r2 = np.zeros(12, dtype=np.uint64)
+        for _ in range(50):
+            a0, a1, b0, b1 = (rng.randrange(p_) for _ in range(4))
+            A = np.concatenate([enc(a0 * Rm % p_), enc(a1 * Rm % p_)]); B = np.concatenate([enc(b0 * Rm % p_), enc(b1 * Rm % p_)])
+            hc.hc_hostfast_fp2_mul(which, q(A), q(B), q(r2), 0)
+            assert (dec(r2[:6]), dec(r2[6:])) == ((a0 * b0 - beta * a1 * b1) % p_ * Rm % p_, (a0 * b1 + a1 * b0) % p_ * Rm % p_)
+            hc.hc_hostfast_fp2_mul(which, q(A), q(B), q(r2), 1)
+            d = pow((a0 * a0 + beta * a1 * a1) % p_, -1, p_)
+            assert (dec(r2[:6]), dec(r2[6:])) == (a0 * d % p_ * Rm % p_, (-a1 * d) % p_ * Rm % p_)
