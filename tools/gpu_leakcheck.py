@@ -17,6 +17,22 @@ def cycle(k):
         fw = 6 if curve == "bw6761" else 4
         rs = np.zeros((2, fw), dtype=np.uint64); rs[0, 0], rs[1, 0] = 5, 7
         key.prove(cs.witness(), rs[0], rs[1]); key.free(); cs.free()
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+BLOB = bytes.fromhex(open(os.path.join(GOLDEN, "kzg_blobdata1.txt")).read().strip())
+_cycle_core = cycle
+def cycle(k):
+    _cycle_core(k)
+    # the handle types added later: KZG setup, committed / imported keys, batched MSM
+    ks = pkg.KzgSetup.from_file(ctx, os.path.join(GOLDEN, "kzg_trusted_setup.txt"))
+    ks.compute_commitment(BLOB); ks.compute_proof(BLOB, 1234 + k); ks.compute_cell_proofs(BLOB); ks.close()
+    cs = pkg.R1CS(3, 3000, 9, n_committed=100); key = pkg.Groth16Key(ctx, cs, 9)
+    rs = np.zeros((2, 4), dtype=np.uint64); rs[0, 0], rs[1, 0] = 5, 7
+    key.prove_committed(cs.witness(), rs[0], rs[1]); key.free(); cs.free()
+    cs = pkg.R1CS(3, 3000, 3); key = pkg.Groth16Key(ctx, cs, 9)
+    ik = pkg.ImportedKey(ctx, key.log_n, cs.n_wires, key.export_arrays(cs.n_wires, cs.n_public))
+    z = np.zeros((3000, 4), dtype=np.uint64)
+    ik.prove_solved(cs.witness(), z, z, z, rs[0], rs[1]); ik.free(); key.free(); cs.free()
+    pts = ctx.synthetic_g1(k, 2000); ctx.msm_g1_batched(pts, np.zeros((3, 2000, 4), dtype=np.uint64)); pts.free()
 cycle(0); cycle(1)                      # warm up: workspaces of the lanes grow to their final size
 torch.cuda.synchronize()
 f0 = torch.cuda.mem_get_info()[0]
