@@ -365,6 +365,8 @@ class Bw6761:
               0x5bbdc19380f7c707f6fe8680ef10cd46fa210a92bc4f56f1b92ab610ecb3fd508160dc51bab3ee5072aa3dedbe0766414556817439a0fbc33df16a239fc281edec5df53182dcf168c9171615a79353ac90858b4a2f2d20aeae7ededaead5b0)
     def g1_mul(self, a, k): return self.mul(a, k)
     def g2_mul(self, a, k): return self.mul(a, k)
+    def g1_add(self, a, c): return self.add(a, c)
+    def g2_add(self, a, c): return self.add(a, c)
     def g1_to_limbs(self, pt): return self.to_limbs(pt)
     def g2_to_limbs(self, pt): return self.to_limbs(pt)
 

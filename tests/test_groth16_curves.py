@@ -128,7 +128,7 @@ def test_imported_key_on_other_curves(ctx, pkg, S):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("curve", ["bls12381", "bls12377"])
+@pytest.mark.parametrize("curve", ["bls12381", "bls12377", "bw6761"])
 def test_device_proof_passes_groth16_verify(ctx, pkg, curve):
     """Prove -> verify on BLS12-381 and on the voteverifier curve BLS12-377 with the library's own verifying key:
     e(A, B) == e(alpha, beta) e(vk_x, gamma) e(C, delta) over big-int pairings (the BLS12-381 one is pinned on the reference's
@@ -137,23 +137,33 @@ def test_device_proof_passes_groth16_verify(ctx, pkg, curve):
     if curve == "bls12381":
         from oracle import bls12381_pairing_py as BP
         S = cp.BLS12_381
-    else:
+    elif curve == "bls12377":
         from oracle import bls12377_pairing_py as BP
         S = cp.BLS12_377
         e = BP.pairing(S.g2_gen, S.g1_gen)
         assert not (e == BP.F12.one()) and e ** S.r == BP.F12.one()
         assert BP.pairing(S.g2_mul(S.g2_gen, 5), S.g1_mul(S.g1_gen, 3)) == e ** 15
+    else:                                         # the aggregator curve: embedding degree 6, both groups over Fp
+        from oracle import bw6761_pairing_py as BP
+        S = cp.BW6_761
+        e = BP.pairing(S.g2_gen, S.g1_gen)
+        assert not (e == BP.F6.one()) and e ** S.r == BP.F6.one()
+        assert BP.pairing(S.g2_mul(S.g2_gen, 5), S.g1_mul(S.g1_gen, 3)) == e ** 15
     n_constraints, n_public = 400, 4
     cs = pkg.R1CS(3, n_constraints, n_public, curve=curve)
     key = pkg.Groth16Key(ctx, cs, 9)
     vk = key.verifying_key(n_public)
+    fw = 12 if curve == "bw6761" else 6           # uint64 words per base-field element
+    rinv = pow(1 << (64 * fw), -1, S.p)
     def fp(words):
-        return S.fp_from_mont(int(sum(int(w) << (64 * i) for i, w in enumerate(words))))
+        return int(sum(int(w) << (64 * i) for i, w in enumerate(words))) * rinv % S.p
     def g1(l):
         l = [int(v) for v in l]
-        return None if not any(l) else (fp(l[0:6]), fp(l[6:12]))
+        return None if not any(l) else (fp(l[0:fw]), fp(l[fw:2 * fw]))
     def g2(l):
         l = [int(v) for v in l]
+        if curve == "bw6761":
+            return None if not any(l) else (fp(l[0:fw]), fp(l[fw:2 * fw]))
         return None if not any(l) else ((fp(l[0:6]), fp(l[6:12])), (fp(l[12:18]), fp(l[18:24])))
     w = cs.witness()
     r, s = S.fr_at(2, 0), S.fr_at(2, 1)
