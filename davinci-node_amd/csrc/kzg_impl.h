@@ -11,7 +11,7 @@
 // the 128 cell proofs are ONE batched MSM -- 128 quotient polynomials (synthetic division by X^64 - h_k^64, one thread per
 // (cell, residue class)) committed over the same 4032 monomial points, every (cell, window) pair a virtual window of one
 // sorted entry list -- instead of FK20's Toeplitz/EC-FFT pipeline: KZG proofs are unique group elements, the bytes are the
-// same.  Window combine, affine normalisation and ZCash compression run on the device; 48 bytes per point come back.
+// same.  The result points (24 KiB for 128 proofs) are normalised with one shared inversion and ZCash-compressed on the host.
 #pragma once
 #include "suite_api.h"
 
@@ -46,13 +46,6 @@ template <int W> __device__ __forceinline__ void be_to_words(const uint8_t* b, u
     for (int i = 0; i < W; ++i) {
         const uint8_t* p = b + 4 * (W - 1 - i);
         w[i] = ((u32)p[0] << 24) | ((u32)p[1] << 16) | ((u32)p[2] << 8) | (u32)p[3];
-    }
-}
-template <int W> __device__ __forceinline__ void words_to_be(const u32 (&w)[W], uint8_t* b) {
-#pragma unroll
-    for (int i = 0; i < W; ++i) {
-        uint8_t* p = b + 4 * (W - 1 - i);
-        p[0] = (uint8_t)(w[i] >> 24); p[1] = (uint8_t)(w[i] >> 16); p[2] = (uint8_t)(w[i] >> 8); p[3] = (uint8_t)w[i];
     }
 }
 // y > (p - 1)/2  <=>  2y > p (p odd), y a canonical integer
@@ -261,19 +254,6 @@ static __global__ void k_cell_quotients(const u32* __restrict__ coef_ext, const 
     }
 }
 
-// ---- result points: internal xyzz -> 48-byte ZCash-compressed G1 (what KZGCommitment / KZGProof hold, types/blobs.go:165,199)
-static __global__ void k_g1_compress(const u32* __restrict__ xyzz, u32 n, uint8_t* __restrict__ out) {
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint8_t* b = out + (size_t)48 * i;
-    const Cv::X p = ld_xyzz<Cv>(xyzz + (size_t)i * Cv::XW);
-    if (Cv::is_inf(p)) { b[0] = 0xC0; for (int k = 1; k < 48; ++k) b[k] = 0; return; }
-    const Cv::A a = Cv::to_affine(p);
-    u32 w[BW];
-    fe_pack<B>(to_integer<B>(a.x), w);
-    words_to_be<BW>(w, b);
-    b[0] |= 0x80 | (lexicographically_largest(to_integer<B>(a.y)) ? 0x20 : 0x00);
-}
 }  // namespace kzg
 
 struct dvn_kzg_setup {
@@ -379,21 +359,34 @@ static int32_t kzg_load_blob(dvn_ctx* ctx, const dvn_kzg_setup* s, const uint8_t
     if (herr) return fail(DVN_ERR_INVALID_ARG, "blob element is not a canonical field element");
     return DVN_OK;
 }
-// ---- host finishing of ONE result point (host_fast.h, 6 x 64-bit limbs): a 381-bit Fermat inversion is ~25 us here against 0.6 ms
-// for one GPU lane, so a single commitment / opening proof is normalised and compressed on the host, the 128 cell proofs -- 128
-// independent inversions -- on the device.  w: internal xyzz image (4 x 12 u32 words) -> 48 compressed bytes.
-static void kzg_compress_xyzz_host(const u32* w, uint8_t out[48]) {
+// ---- host finishing of the result points (host_fast.h, 6 x 64-bit limbs): affine normalisation with ONE shared inversion
+// (Montgomery's trick over ZZ_i * ZZZ_i) and ZCash compression.  A 381-bit Fermat inversion is ~25 us here against 0.6 ms for a GPU
+// lane, and 128 results are 24 KiB: cheaper to bring back than to invert on the device.  xyzz: n internal images (4 x 12 u32 words).
+static void kzg_compress_xyzz_host(const u32* xyzz, u32 n, uint8_t* out48) {
     typedef dvn_host::OpsFqN<Fp381Cfg, 6> O;
     typedef dvn_host::Group<O> HG;
-    const HG::X pnt = HG::load_device(w);
-    if (HG::is_inf(pnt)) { memset(out, 0, 48); out[0] = 0xC0; return; }
-    const HG::X a = HG::normalize(pnt);
+    std::vector<HG::X> pt(n);
+    std::vector<O::F> pre(n);                                  // prefix products of d_i = ZZ_i * ZZZ_i over the finite points
+    O::F run = O::one();
+    for (u32 i = 0; i < n; ++i) {
+        pt[i] = HG::load_device(xyzz + (size_t)i * G1_381::XW);
+        pre[i] = run;
+        if (!HG::is_inf(pt[i])) run = O::mul(run, O::mul(pt[i].zz, pt[i].zzz));
+    }
+    O::F inv_run = O::inv(run);
     O::F one_int = O::zero(); one_int.l[0] = 1;
-    const O::F x = O::mul(a.x, one_int), y = O::mul(a.y, one_int);                 // Montgomery -> canonical integers
-    for (int i = 0; i < 6; ++i) for (int k = 0; k < 8; ++k) out[8 * (5 - i) + (7 - k)] = (uint8_t)(x.l[i] >> (8 * k));
-    const O::F y2 = O::add(y, y);                                                    // 2y mod p = 2y - p iff 2y > p: odd then (p odd)
-    const bool largest = !O::is_zero(y) && (y2.l[0] & 1);
-    out[0] |= 0x80 | (largest ? 0x20 : 0x00);
+    for (int i = (int)n - 1; i >= 0; --i) {
+        uint8_t* out = out48 + (size_t)48 * i;
+        if (HG::is_inf(pt[i])) { memset(out, 0, 48); out[0] = 0xC0; continue; }
+        const O::F dinv = O::mul(inv_run, pre[i]);                                    // 1 / (ZZ_i ZZZ_i)
+        inv_run = O::mul(inv_run, O::mul(pt[i].zz, pt[i].zzz));
+        const O::F x = O::mul(O::mul(pt[i].x, O::mul(dinv, pt[i].zzz)), one_int);     // X / ZZ, canonical integer
+        const O::F y = O::mul(O::mul(pt[i].y, O::mul(dinv, pt[i].zz)), one_int);      // Y / ZZZ
+        for (int j = 0; j < 6; ++j) for (int k = 0; k < 8; ++k) out[8 * (5 - j) + (7 - k)] = (uint8_t)(x.l[j] >> (8 * k));
+        const O::F y2 = O::add(y, y);                                                   // 2y mod p is odd iff 2y > p (p odd)
+        const bool largest = !O::is_zero(y) && (y2.l[0] & 1);
+        out[0] |= 0x80 | (largest ? 0x20 : 0x00);
+    }
 }
 
 // `batch` MSMs of n scalars each over pts[0, n) (expanded table `tab`, window c) -> `batch` compressed points in out48
@@ -401,21 +394,12 @@ static void kzg_compress_xyzz_host(const u32* w, uint8_t out[48]) {
 static int32_t kzg_commit(dvn_ctx* ctx, const dvn_kzg_setup* s, const dvn_points* pts, const u32* tab, u32 c, size_t n, const u32* d_scalars, u32 batch, uint8_t* out48) {
     MsmLane* L = nullptr;
     TRY(msm_batched_submit<G1_381>(ctx, pts, 0, n, d_scalars, batch, c, s->d_res, &L, tab));
-    if (batch == 1) {                                                  // one point: normalise + compress on the host
-        u32 h[G1_381::XW];
-        hipError_t e1 = hipMemcpyAsync(h, s->d_res, sizeof(h), hipMemcpyDeviceToHost, L->stream);
-        int32_t rc1 = lane_wait(ctx, *L);
-        if (e1 != hipSuccess) { (void)hipGetLastError(); return fail(DVN_ERR_DEVICE, "result copy failed: %s", hipGetErrorString(e1)); }
-        TRY(rc1);
-        kzg_compress_xyzz_host(h, out48);
-        return DVN_OK;
-    }
-    uint8_t* d_out = s->d_bytes + (size_t)kzg::N * 40;                 // tail of the staging buffer (6 KiB needed)
-    kzg::k_g1_compress<<<(batch + 63) / 64, 64, 0, L->stream>>>(s->d_res, batch, d_out);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(out48, d_out, (size_t)batch * 48, hipMemcpyDeviceToHost, L->stream);
+    std::vector<u32> h((size_t)batch * G1_381::XW);
+    hipError_t e1 = hipMemcpyAsync(h.data(), s->d_res, h.size() * 4, hipMemcpyDeviceToHost, L->stream);
     int32_t rc = lane_wait(ctx, *L);
-    if (e != hipSuccess) { (void)hipGetLastError(); return fail(DVN_ERR_DEVICE, "compression failed: %s", hipGetErrorString(e)); }
+    if (e1 != hipSuccess) { (void)hipGetLastError(); return fail(DVN_ERR_DEVICE, "result copy failed: %s", hipGetErrorString(e1)); }
+    TRY(rc);
+    kzg_compress_xyzz_host(h.data(), batch, out48);
     return rc;
 }
 
