@@ -339,7 +339,7 @@ extern "C" int32_t dvn_kzg_setup_load(dvn_ctx* ctx, const uint8_t* g1_lagrange, 
         (g1_monomial && (rc = kzg_points_from_compressed(ctx, s, g1_monomial, 0, &s->monomial)))) { kzg_setup_destroy(s); return rc; }
     // expanded tables, once per setup: window sizes from the sweep in tools/gpu_kzg_perf.py (DVN_KZG_C / DVN_KZG_CELL_C override)
     auto env_c = [](const char* name, u32 dflt) { const char* v = getenv(name); const int x = v ? atoi(v) : 0; return (u32)((x >= 4 && x <= 16) ? x : dflt); };
-    s->c_single = env_c("DVN_KZG_C", 13); s->c_cells = env_c("DVN_KZG_CELL_C", 11);
+    s->c_single = env_c("DVN_KZG_C", 13); s->c_cells = env_c("DVN_KZG_CELL_C", 13);
     if ((rc = msm_row_table_create<G1_381>(ctx, s->lagrange_brp, kzg::N, s->c_single, &s->rows_single, &s->tab_lagrange)) ||
         (g1_monomial && (rc = msm_row_table_create<G1_381>(ctx, s->monomial, kzg::QN, s->c_cells, &s->rows_cells, &s->tab_monomial)))) { kzg_setup_destroy(s); return rc; }
     *out = s;
