@@ -65,7 +65,10 @@ static inline void expand_plan(size_t n, u32 scalar_bits, size_t point_bytes, u3
     static const size_t max_bytes = []() { const char* v = getenv("DVN_MSM_EXPAND_MAX_GB"); return (size_t)(v ? atoi(v) : 16) << 30; }();
     *c = 0; *nexp = 1;
     if (!enabled || n < ((size_t)1 << 15)) return;
-    const u32 cc = n >= ((size_t)1 << 20) ? 20 : n >= ((size_t)1 << 18) ? 17 : 16;
+    u32 cc = n >= ((size_t)1 << 20) ? 20 : n >= ((size_t)1 << 18) ? 17 : 16;
+    // a top row of only a few bits (255 = 15 * 17 + 0: nothing but carries; 377 = 22 * 17 + 3) piles a large share of all entries
+    // into a handful of buckets: take the next window size whose top row holds at least 8 bits
+    while (scalar_bits % cc < 8 && cc < 21) ++cc;
     const u32 rows = scalar_bits / cc + 1;
     if ((size_t)rows * n * point_bytes > max_bytes || (size_t)rows * n >= ((size_t)1 << 31)) return;
     *c = cc; *nexp = rows;
