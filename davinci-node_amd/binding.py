@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 DIF, DIT = 0, 1
 MSM_SCALARS_ON_DEVICE = 1
+MSM_STATIC_MAX_N = 65536
 NTT_DATA_ON_DEVICE = 1
 
 _U64P = C.POINTER(C.c_uint64)
@@ -63,6 +64,7 @@ def load_library():
         "dvn_points_len": (sz, [vp]),
         "dvn_points_free": (i32, [vp, vp]),
         "dvn_msm_g1": (i32, [vp, vp, sz, sz, vp, u32, vp]),
+        "dvn_msm_g1_static": (i32, [vp, vp, sz, sz, vp, u32, vp]),
         "dvn_msm_g2": (i32, [vp, vp, sz, sz, vp, u32, vp]),
         "dvn_msm_g1_batched": (i32, [vp, vp, sz, sz, vp, u32, u32, vp]),
         "dvn_msm_g1_submit": (i32, [vp, vp, sz, sz, vp, u32, C.POINTER(i32)]),
@@ -175,7 +177,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "dvn_init", "dvn_shutdown", "dvn_last_error", "dvn_version", "dvn_malloc", "dvn_free", "dvn_memcpy_h2d",
     "dvn_memcpy_d2h", "dvn_synchronize", "dvn_points_upload_g1", "dvn_points_upload_g2", "dvn_points_synthetic_g1",
-    "dvn_points_synthetic_g2", "dvn_scalars_synthetic", "dvn_points_set_expanded", "dvn_points_download", "dvn_points_len", "dvn_points_free", "dvn_msm_g1", "dvn_msm_g2", "dvn_msm_g1_batched",
+    "dvn_points_synthetic_g2", "dvn_scalars_synthetic", "dvn_points_set_expanded", "dvn_points_download", "dvn_points_len", "dvn_points_free", "dvn_msm_g1", "dvn_msm_g1_static", "dvn_msm_g2", "dvn_msm_g1_batched",
     "dvn_msm_g1_submit", "dvn_msm_g1_collect", "dvn_msm_g2_submit", "dvn_msm_g2_collect", "dvn_msm_plan", "dvn_msm_plan_points", "dvn_msm_g1_windows", "dvn_msm_g1_windows_submit", "dvn_msm_g1_windows_collect", "dvn_msm_combine_g1", "dvn_ntt_domain", "dvn_ntt_domain_free", "dvn_ntt",
     "dvn_groth16_compute_h", "dvn_last_kernel_ms", "dvn_r1cs_synthetic", "dvn_r1cs_info", "dvn_r1cs_witness", "dvn_r1cs_free",
     "dvn_groth16_setup", "dvn_groth16_pk_info", "dvn_groth16_pk_free", "dvn_groth16_prove", "dvn_groth16_last_ms", "dvn_groth16_prove_shard", "dvn_groth16_prove_combine",
@@ -319,6 +321,12 @@ class Context:
         sp, ns, fl = self._scalars(scalars, n)
         out = np.zeros(12, dtype=np.uint64)
         self._chk(self.L.dvn_msm_g1(self.h, pts.handle, off, ns, sp, fl, _host(out)))
+        return out
+
+    def msm_g1_static(self, pts: Points, d_scalars: int, n: int, off: int = 0, flags: int = MSM_SCALARS_ON_DEVICE) -> np.ndarray:
+        """dvn_msm_g1 over the library's static scratch buffer (no allocation): device scalars, n <= MSM_STATIC_MAX_N."""
+        out = np.zeros(12, dtype=np.uint64)
+        self._chk(self.L.dvn_msm_g1_static(self.h, pts.handle, off, n, C.c_void_p(int(d_scalars)), flags, _host(out)))
         return out
 
     def msm_g1_batched(self, pts: Points, scalars: np.ndarray, off: int = 0) -> np.ndarray:

@@ -41,6 +41,7 @@ extern "C" int32_t dvn_init(const int* devs, int ndev, dvn_ctx** out) {
         if (e2 == hipSuccess) e2 = hipHostMalloc((void**)&L.h_sums, DVN_HSUMS_WORDS * 4, hipHostMallocDefault);
     }
     if (e2 != hipSuccess) { delete ctx; (void)hipGetLastError(); return fail(DVN_ERR_DEVICE, "context setup failed: %s", hipGetErrorString(e2)); }
+    { int32_t rc = dvn_internal_static_scratch_init(ctx); if (rc != DVN_OK) { dvn_shutdown(ctx); return rc; } }
     *out = ctx;
     return DVN_OK;
 }

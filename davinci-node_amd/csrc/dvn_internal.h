@@ -1,6 +1,7 @@
 // Internal declarations shared by the translation units of libdvn_prover.so (not part of the C-ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -27,6 +28,9 @@ struct MsmLane {
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     void* ws = nullptr; size_t ws_bytes = 0;
+    // caller-independent workspace for the allocation-free entry point: when set, the MSM carves its scratch out of this
+    // fixed buffer instead of the grow-only `ws` (never hipMalloc / hipFree) and clears memory with a fill kernel
+    void* ext_ws = nullptr; size_t ext_bytes = 0;
     u32* h_sums = nullptr;        // pinned host buffer for the per-window sums
     bool busy = false;
     int curve = 0; bool expanded = false; u32 c = 0, nwin = 0, W = 0; u32 seq = 0;
@@ -46,6 +50,8 @@ struct dvn_ctx {
     size_t ws_bytes = 0;
     std::mutex mu;
     bool force_fail = false;
+    // this device's copy of the library's static scratch array (resolved once at dvn_init with hipGetSymbolAddress)
+    void* static_ws = nullptr; size_t static_ws_bytes = 0;
 };
 struct dvn_points {
     int suite = 0;            // 0 = BN254, 1 = BLS12-377
@@ -115,6 +121,10 @@ static inline int32_t ensure_ws(dvn_ctx* ctx, size_t bytes) {
     return DVN_OK;
 }
 static inline int32_t lane_ensure_ws(MsmLane& L, size_t bytes) {
+    if (L.ext_ws) {
+        if (bytes > L.ext_bytes) return fail(DVN_ERR_INVALID_ARG, "MSM needs %zu bytes of scratch, the static scratch buffer holds %zu", bytes, L.ext_bytes);
+        return DVN_OK;
+    }
     if (bytes <= L.ws_bytes) return DVN_OK;
     if (L.ws) { HIP_TRY(hipStreamSynchronize(L.stream)); HIP_TRY(hipFree(L.ws)); L.ws = nullptr; L.ws_bytes = 0; }
     size_t want = align_up(bytes + bytes / 8, 1 << 20);
@@ -122,6 +132,7 @@ static inline int32_t lane_ensure_ws(MsmLane& L, size_t bytes) {
     L.ws_bytes = want;
     return DVN_OK;
 }
+static inline void* lane_ws_base(const MsmLane& L) { return L.ext_ws ? L.ext_ws : L.ws; }
 struct Carver {
     char* base; size_t off = 0;
     explicit Carver(void* b) : base((char*)b) {}
@@ -176,6 +187,9 @@ static inline G2::A g2_generator() {   // EIP-197 generator, gnark Montgomery im
     return G2::affine_from_ext((const u32*)g);
 }
 
+
+// resolves this device's address of the static scratch array (dvn_msm_g1.hip); called by dvn_init with the device current
+int32_t dvn_internal_static_scratch_init(dvn_ctx* ctx);
 
 // ---- internal cross-TU entry points (caller holds ctx->mu) -------------------------------------------------
 // MSM with DEVICE scalars, result as a host (4x64-limb, R = 2^256) extended-Jacobian point (dvn_msm_g1.hip / dvn_msm_g2.hip)

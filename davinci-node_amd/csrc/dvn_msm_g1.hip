@@ -15,6 +15,43 @@ extern "C" int32_t dvn_msm_g1(dvn_ctx* ctx, const dvn_points* pts, size_t off, s
     return msm_full<G1>(ctx, pts, 1, off, n, scalars, flags, out_jac);
 }
 
+// ---- the entry point that allocates nothing ----------------------------------------------------------------------------
+// dvn_msm_g1 keeps its sort / bucket / partial-sum arrays in a grow-only hipMalloc'ed workspace.  Callers that cannot allocate
+// (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc) get the same MSM over a FIXED scratch
+// buffer: a file-scope device array of DVN_MSM_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the
+// process ends.  Its device address differs per GPU: it is resolved once per context (= per device) at dvn_init, with that
+// device current, and only that pointer -- never the array's name -- is handed to kernels and fills.
+static constexpr size_t DVN_MSM_STATIC_SCRATCH_BYTES = (size_t)64 << 20;
+static __device__ __align__(256) unsigned char scratch[DVN_MSM_STATIC_SCRATCH_BYTES];
+
+int32_t dvn_internal_static_scratch_init(dvn_ctx* ctx) {
+    void* p = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return fail(DVN_ERR_DEVICE, "hipGetSymbolAddress returned a NULL scratch address on device %d", ctx->device);
+    ctx->static_ws = p; ctx->static_ws_bytes = DVN_MSM_STATIC_SCRATCH_BYTES;
+    return DVN_OK;
+}
+// Same result as dvn_msm_g1 (same kernels), n <= DVN_MSM_STATIC_MAX_N, scalars already in device memory.  No hipMalloc / hipFree:
+// scratch comes from the static array, clears are fill kernels, the result leaves through the lane's pinned buffer of dvn_init.
+// All calls on one GPU share that GPU's array (it keeps the previous call's contents; everything that must start at zero is
+// cleared per call): calls that overlap on one GPU -- two contexts on the same device -- race.
+extern "C" int32_t dvn_msm_g1_static(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* d_scalars_mont,
+                                     uint32_t flags, uint64_t out_jac[12]) {
+    TRY(enter(ctx));
+    if (!pts || !out_jac || (!d_scalars_mont && n)) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    if (pts->curve != 1 || pts->suite != 0) return fail(DVN_ERR_INVALID_ARG, "point set is not BN254 G1");
+    if (!(flags & DVN_MSM_SCALARS_ON_DEVICE)) return fail(DVN_ERR_INVALID_ARG, "dvn_msm_g1_static takes device scalars only (DVN_MSM_SCALARS_ON_DEVICE): a host copy could allocate staging memory");
+    if (n > DVN_MSM_STATIC_MAX_N) return fail(DVN_ERR_INVALID_ARG, "n = %zu exceeds DVN_MSM_STATIC_MAX_N = %u, the most the %zu-byte static scratch buffer serves", n, (unsigned)DVN_MSM_STATIC_MAX_N, DVN_MSM_STATIC_SCRATCH_BYTES);
+    typedef FastHost<G1>::G HG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    MsmLane* L = nullptr;
+    TRY(msm_submit<G1>(ctx, pts, off, n, d_scalars_mont, flags, &L, /*static_scratch=*/true));
+    HG::X r;
+    TRY(msm_collect<G1>(ctx, *L, &r));
+    HG::write_jac(r, out_jac);
+    return DVN_OK;
+}
+
 // B MultiExps over ONE point set in one pass of the pipeline: every (vector, window) pair is a virtual window of the same
 // sorted entry list (msm_driver.h msm_windows_staged, batched mode), the window sums are combined per vector on the device.
 // For many commitments over one basis (a PLONK prover's wire / quotient polynomials over one SRS, several BSB22 commitments

@@ -186,6 +186,20 @@ template <class D> static int32_t sort_attrs() {
 static inline size_t s1_lds(u32 lb) { return ((size_t)3 * lb + 80 + 2 * ST) * 4; }
 static inline size_t s2_lds() { return ((size_t)4 * 1024 + 80 + ST) * 4 + (size_t)ST * 2; }
 
+// zero `bytes` (a multiple of 4) on the lane's stream: hipMemsetAsync, or a fill kernel on the allocation-free path (callers
+// that may sit under HIP graph capture, where recorded memset nodes are to be avoided)
+static __global__ void k_zero_words(u32* __restrict__ p, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) p[i] = 0;
+}
+static inline int32_t lane_zero(MsmLane& L, void* p, size_t bytes, hipStream_t st) {
+    if (!L.ext_ws) { HIP_TRY(hipMemsetAsync(p, 0, bytes, st)); return DVN_OK; }
+    const size_t words = bytes / 4;
+    const unsigned blocks = (unsigned)std::min<size_t>((words + 255) / 256, 2048);
+    k_zero_words<<<blocks ? blocks : 1, 256, 0, st>>>((u32*)p, words);
+    HIP_TRY(hipGetLastError());
+    return DVN_OK;
+}
+
 // Plain point sets, two-pass staged sort: one globally sorted entry list over the virtual buckets (window, bucket);
 // the accumulate / fix kernels see ONE window of W * nb buckets, the reduction runs per real window afterwards.
 template <class Cv>
@@ -234,7 +248,7 @@ static int32_t msm_windows_staged(dvn_ctx* ctx, MsmLane& L, const dvn_points* pt
     cs.take((size_t)nseg * Cv::XW * 4); cs.take((size_t)nseg * Cv::XW * 4);
     cs.take((size_t)W * bpw * Cv::XW * 4); cs.take((size_t)W * Cv::XW * 4);
     TRY(lane_ensure_ws(L, cs.off + 8192));
-    Carver cv(L.ws);
+    Carver cv(lane_ws_base(L));
     const u32* d_scalars;
     if (!on_dev) {
         u32* tmp = cv.take<u32>(n * (SB / 4));
@@ -271,7 +285,7 @@ static int32_t msm_windows_staged(dvn_ctx* ctx, MsmLane& L, const dvn_points* pt
     if (dbg) { fprintf(stderr, "[dvn] msm(staged) n=%zu c=%u W=%u nb=%u lob=%u lb=%u seg=%u nseg=%u tpw=%u ws=%zu\n", n, c, W, nb, lob, lb, seg, nseg, tpw, cs.off); fflush(stderr); }
     TRY(sort_attrs<int16_t>());
     HIP_TRY(hipEventRecord(L.ev[0], st));
-    HIP_TRY(hipMemsetAsync(totals, 0, 16, st));
+    TRY(lane_zero(L, totals, 16, st));
     if (batched) k_digits16_batched<typename ScalarOf<Cv>::S><<<(unsigned)((n_src * batch + 255) / 256), 256, 0, st>>>(d_scalars, n_src, batch, c, win_hi, digits);
     else k_digits16<typename ScalarOf<Cv>::S><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_scalars, n, c, win_lo, win_hi, digits);
     DBG_SYNC("k_digits16");
@@ -283,7 +297,7 @@ static int32_t msm_windows_staged(dvn_ctx* ctx, MsmLane& L, const dvn_points* pt
     DBG_SYNC("k_p1_scan");
     k_s1_scatter<int16_t><<<W * tpw, 1024, s1_lds(lb), st>>>(digits, n, tpw, 1u, lob, lb, 0u, 0u, win_lo, hist1, bin_base, p1_ref, p1_lo);
     DBG_SYNC("k_s1_scatter");
-    HIP_TRY(hipMemsetAsync(counts, 0, (size_t)vb * 8, st));             // counts + cursor
+    TRY(lane_zero(L, counts, (size_t)vb * 8, st));             // counts + cursor
     k_s2_pieces<<<1, 1024, 0, st>>>(bin_base, hbins, piece_base);
     DBG_SYNC("k_s2_pieces");
     k_s2_count<<<max_pieces, 1024, 0, st>>>(bin_base, piece_base, hbins, p1_lo, lob, counts);
@@ -378,7 +392,7 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
     cs.take((size_t)nseg * Cv::XW * 4); cs.take((size_t)nseg * Cv::XW * 4);
     cs.take((size_t)bpw * Cv::XW * 4); cs.take((size_t)Cv::XW * 4);
     TRY(lane_ensure_ws(L, cs.off + 8192));
-    Carver cv(L.ws);
+    Carver cv(lane_ws_base(L));
     const u32* d_scalars;
     if (!on_dev) {
         u32* tmp = cv.take<u32>(n * (SB / 4));
@@ -413,7 +427,7 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
     if (dbg) { fprintf(stderr, "[dvn] msm(expanded) n=%zu c=%u W=%u nb=%u lob=%u lb=%u seg=%u nseg=%u tpw=%u ws=%zu\n", n, c, W, nb, lob, lb, seg, nseg, tpw, cs.off); fflush(stderr); }
     TRY(sort_attrs<int>());
     HIP_TRY(hipEventRecord(L.ev[0], st));
-    HIP_TRY(hipMemsetAsync(totals, 0, 16, st));
+    TRY(lane_zero(L, totals, 16, st));
     k_digits32<typename ScalarOf<Cv>::S><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_scalars, n, c, win_lo, win_hi, digits);
     DBG_SYNC("k_digits32");
     k_s1_hist<int><<<W * tpw, 1024, (size_t)lb * 4, st>>>(digits, n, tpw, lob, lb, hist1);
@@ -424,7 +438,7 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
     DBG_SYNC("k_p1_scan");
     k_s1_scatter<int><<<W * tpw, 1024, s1_lds(lb), st>>>(digits, n, tpw, 0u, lob, lb, (u32)off, (u32)pts->n, win_lo, hist1, bin_base, p1_ref, p1_lo);
     DBG_SYNC("k_s1_scatter");
-    HIP_TRY(hipMemsetAsync(counts, 0, (size_t)nb * 8, st));             // counts + cursor
+    TRY(lane_zero(L, counts, (size_t)nb * 8, st));             // counts + cursor
     k_s2_pieces<<<1, 1024, 0, st>>>(bin_base, lb, piece_base);
     DBG_SYNC("k_s2_pieces");
     k_s2_count<<<max_pieces, 1024, 0, st>>>(bin_base, piece_base, lb, p1_lo, lob, counts);
@@ -554,6 +568,7 @@ static inline int32_t lane_acquire(dvn_ctx* ctx, MsmLane** out) {
             HIP_TRY(hipEventRecord(ctx->ev_dep, ctx->stream));
             HIP_TRY(hipStreamWaitEvent(L.stream, ctx->ev_dep, 0));
             L.busy = true; L.seq++;
+            L.ext_ws = nullptr; L.ext_bytes = 0;
             *out = &L;
             return DVN_OK;
         }
@@ -571,10 +586,13 @@ static inline int32_t lane_wait(dvn_ctx* ctx, MsmLane& L) {
 }
 // queue a full MSM (all windows) on a free lane; *lane_out identifies it
 template <class Cv>
-static int32_t msm_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags, MsmLane** lane_out) {
+static int32_t msm_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags, MsmLane** lane_out,
+                          bool static_scratch = false) {
     if (off > pts->n || n > pts->n - off) return fail(DVN_ERR_INVALID_ARG, "len(points) != len(scalars): range [%zu, %zu) outside point set of %zu", off, off + n, pts->n);
+    if (static_scratch && !ctx->static_ws) return fail(DVN_ERR_DEVICE, "static scratch buffer was not resolved at dvn_init");
     MsmLane* L = nullptr;
     TRY(lane_acquire(ctx, &L));
+    if (static_scratch) { L->ext_ws = ctx->static_ws; L->ext_bytes = ctx->static_ws_bytes; }
     L->curve = pts->curve; L->W = 0;
     int32_t rc = DVN_OK;
     if (n == 0) { L->nwin = 0; }

@@ -381,6 +381,18 @@ int32_t dvn_sha256(const uint8_t* data, size_t len, uint8_t out[32]);        /* 
 int32_t dvn_kzg_compute_cell_proofs(dvn_ctx* ctx, const dvn_kzg_setup* setup, const uint8_t* blob, uint8_t* proofs /* 128 x 48 */);
 int32_t dvn_kzg_evaluate_barycentric(dvn_ctx* ctx, const dvn_kzg_setup* setup, const uint8_t* blob, const uint8_t z[32], uint8_t y[32]);
 
+/* ---- the entry point that allocates nothing ------------------------------------------------------------------------
+ * No counterpart in the reference: this one is for callers that cannot call hipMalloc -- code under HIP graph capture,
+ * tight serving loops, harnesses that forbid allocation.  Same MSM and same result as dvn_msm_g1, but every scratch array
+ * of the pipeline (digits, sort buffers, bucket sums, edge partials) lives in a fixed 64 MiB device array that the library
+ * holds on each GPU it runs on until the process ends, and memory is cleared by fill kernels.  Limits: n <=
+ * DVN_MSM_STATIC_MAX_N, scalars in DEVICE memory (flags must carry DVN_MSM_SCALARS_ON_DEVICE), BN254 G1; anything beyond
+ * is DVN_ERR_INVALID_ARG with a message that names the limit.  Calls no hipMalloc / hipFree.  Every call on one GPU shares
+ * that GPU's array: calls that overlap on one GPU (two contexts on the same device) race. */
+#define DVN_MSM_STATIC_MAX_N 65536u
+int32_t dvn_msm_g1_static(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* d_scalars_mont,
+                          uint32_t flags, uint64_t out_jac[12]);
+
 /* ---- timing of the last call's kernels, measured with HIP events on the library's own stream ---------- */
 /* which: 0 = whole device section of the last MSM/NTT call, 1 = its dominant kernel (MSM: bucket
  * accumulation; NTT: sum of butterfly passes). */
