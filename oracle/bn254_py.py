@@ -476,10 +476,20 @@ def lagrange_at(domain: Domain, tau: int):
     """L_j(tau) for j = 0..n-1 over the domain {gen^j}."""
     n = domain.n
     zt = (pow(tau, n, R) - 1) % R
-    out, wj = [], 1
+    # zt w^j / (n (tau - w^j)) with the n denominators inverted together (Montgomery's trick, one modular inversion): the
+    # closed-form checker then runs at the benchmarked sizes (n = 2^20) in seconds
+    ws, den, wj = [], [], 1
     for _ in range(n):
-        out.append(zt * wj % R * pow(n * (tau - wj) % R, -1, R) % R)
-        wj = wj * domain.gen % R
+        ws.append(wj); den.append(n * (tau - wj) % R); wj = wj * domain.gen % R
+    assert all(den), "tau lies in the domain"
+    pre, acc = [], 1
+    for d in den:
+        pre.append(acc); acc = acc * d % R
+    inv = pow(acc, -1, R)
+    out = [0] * n
+    for j in range(n - 1, -1, -1):
+        out[j] = zt * ws[j] % R * (inv * pre[j] % R) % R
+        inv = inv * den[j] % R
     return out
 
 
