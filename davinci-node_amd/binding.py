@@ -157,6 +157,24 @@ def load_library():
         "dvn_bw6761_r1cs_synthetic": (i32, [u64, u32, u32, C.POINTER(vp)]),
         "dvn_bw6761_groth16_setup": (i32, [vp, vp, u64, C.POINTER(vp)]),
         "dvn_bw6761_groth16_prove": (i32, [vp, vp, vp, u32, vp, vp, vp]),
+        "dvn_ctx_device_count": (i32, [vp]),
+        "dvn_ctx_device": (vp, [vp, i32]),
+        "dvn_ctx_device_ordinal": (i32, [vp]),
+        "dvn_error_string": (C.c_char_p, [i32]),
+        "dvn_msm_g1_share_submit": (i32, [vp, vp, sz, sz, vp, u32, u32, u32, C.POINTER(i32)]),
+        "dvn_msm_g1_share_collect": (i32, [vp, i32, vp]),
+        "dvn_msm_g1_sum": (i32, [vp, u32, vp]),
+        "dvn_groth16_prove_multi": (i32, [vp, vp, u32, vp, vp, vp, vp]),
+        "dvn_groth16_prove_solved_multi": (i32, [vp, vp, u32, vp, vp, vp, vp, sz, vp, vp, vp]),
+        "dvn_bw6761_groth16_prove_solved_multi": (i32, [vp, vp, u32, vp, vp, vp, vp, sz, vp, vp, vp]),
+        "dvn_groth16_last_stats_json": (i32, [vp, vp, sz, C.POINTER(sz)]),
+        "dvn_bls12377_pedersen_commit": (i32, [vp, vp, vp, vp, sz, u32, vp, vp]),
+        "dvn_bls12381_pedersen_commit": (i32, [vp, vp, vp, vp, sz, u32, vp, vp]),
+        "dvn_bw6761_pedersen_commit": (i32, [vp, vp, vp, vp, sz, u32, vp, vp]),
+        "dvn_gnark_pk_scan": (i32, [vp, sz, vp]),
+        "dvn_groth16_pk_load_bytes": (i32, [vp, vp, sz, u32, vp, u32, C.POINTER(vp)]),
+        "dvn_groth16_pk_load_file": (i32, [vp, C.c_char_p, C.c_char_p, u32, vp, u32, C.POINTER(vp)]),
+        "dvn_groth16_pk_commitment_bases": (i32, [vp, C.POINTER(vp), C.POINTER(vp)]),
         "dvn_prover_use_gpu": (i32, []),
         "dvn_prover_set_use_gpu": (None, [i32]),
         "dvn_prover_reload_env": (None, []),
@@ -197,9 +215,15 @@ EXPORTED_SYMBOLS = [
     "dvn_bw6761_r1cs_synthetic", "dvn_bw6761_groth16_setup", "dvn_bw6761_groth16_prove",
     "dvn_prover_use_gpu", "dvn_prover_set_use_gpu", "dvn_prover_reload_env", "dvn_prover_set_prover", "dvn_prover_set_cpu_backend",
     "dvn_prover_last_backend", "dvn_prover_prove", "dvn_prover_setup",
+    "dvn_ctx_device_count", "dvn_ctx_device", "dvn_ctx_device_ordinal", "dvn_error_string",
+    "dvn_msm_g1_share_submit", "dvn_msm_g1_share_collect", "dvn_msm_g1_sum",
+    "dvn_groth16_prove_multi", "dvn_groth16_prove_solved_multi", "dvn_bw6761_groth16_prove_solved_multi", "dvn_groth16_last_stats_json",
+    "dvn_bls12377_pedersen_commit", "dvn_bls12381_pedersen_commit", "dvn_bw6761_pedersen_commit",
+    "dvn_gnark_pk_scan", "dvn_groth16_pk_load_bytes", "dvn_groth16_pk_load_file", "dvn_groth16_pk_commitment_bases",
 ]
 
-CPU_BACKEND_T = C.CFUNCTYPE(C.c_int32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+# (curve, ccs, pk, witness, r, s, proof, user): what the reference's CPUProverWithWitness receives
+CPU_BACKEND_T = C.CFUNCTYPE(C.c_int32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 PROVER_FUNC_T = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p)
 BN254, BLS12_377, BLS12_381, BW6_761 = 1, 2, 3, 4
 
@@ -249,19 +273,38 @@ class Domain:
 class Context:
     """One context per process-GPU (dvn_init).  Raises DvnError on any failure; never falls back to a CPU path."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device=0, _handle=None, _owner=None):
+        """device: one HIP ordinal, or a list of ordinals (dvn_init(devs, ndev)): the context then serves devs[0] and
+        .device(i) is the context of devs[i]; an ordinal may repeat (two contexts on one GPU)."""
         self.L = load_library()
+        self._owner = _owner
+        if _handle is not None:
+            self.h = _handle
+            return
+        devices = list(device) if isinstance(device, (list, tuple)) else [device]
         h = C.c_void_p()
-        devs = (C.c_int * 1)(device)
-        rc = self.L.dvn_init(devs, 1, C.byref(h))
+        devs = (C.c_int * len(devices))(*devices)
+        rc = self.L.dvn_init(devs, len(devices), C.byref(h))
         if rc != 0:
             raise DvnError(rc, self.L.dvn_last_error(None).decode())
         self.h = h
 
     def close(self):
-        if self.h:
+        if self.h and self._owner is None:
             self.L.dvn_shutdown(self.h)
-            self.h = None
+        self.h = None
+
+    def device_count(self) -> int:
+        return int(self.L.dvn_ctx_device_count(self.h))
+
+    def device(self, index: int) -> "Context":
+        """The context of the index-th device of a multi-device context (0 = this one); owned by this context."""
+        if index == 0:
+            return self
+        h = self.L.dvn_ctx_device(self.h, index)
+        if not h:
+            raise DvnError(-1, self.L.dvn_last_error(self.h).decode())
+        return Context(_handle=C.c_void_p(h), _owner=self)
 
     def _chk(self, rc: int):
         if rc != 0:
@@ -395,6 +438,24 @@ class Context:
         t, w = ticket
         out = np.zeros((w, 16), dtype=np.uint64)
         self._chk(self.L.dvn_msm_g1_windows_collect(self.h, t, _host(out)))
+        return out
+
+    def msm_g1_share_submit(self, pts: Points, d_scalars: int, n: int, rank: int, world: int, off: int = 0) -> int:
+        """Queue this rank's share of an MSM shared by entry count (device scalars); returns the ticket."""
+        t = C.c_int32()
+        self._chk(self.L.dvn_msm_g1_share_submit(self.h, pts.handle, off, n, C.c_void_p(int(d_scalars)), MSM_SCALARS_ON_DEVICE, rank, world, C.byref(t)))
+        return t.value
+
+    def msm_g1_share_collect(self, ticket: int) -> np.ndarray:
+        out = np.zeros(12, dtype=np.uint64)
+        self._chk(self.L.dvn_msm_g1_share_collect(self.h, ticket, _host(out)))
+        return out
+
+    def msm_g1_sum(self, jacs: np.ndarray) -> np.ndarray:
+        """Host only: the sum of G1Jac images (count, 12) -- the shares of all ranks add up to the MSM."""
+        jacs = np.ascontiguousarray(jacs, dtype=np.uint64).reshape(-1, 12)
+        out = np.zeros(12, dtype=np.uint64)
+        self._chk(self.L.dvn_msm_g1_sum(_host(jacs), jacs.shape[0], _host(out)))
         return out
 
     def msm_combine_g1(self, window_sums: np.ndarray, window_bits: int) -> np.ndarray:
@@ -563,6 +624,85 @@ class Groth16Key:
         self.ctx.L.dvn_groth16_last_ms(self.h, C.byref(a), C.byref(b), C.byref(c))
         return {"compute_h": a.value, "msm": b.value, "total": c.value}
 
+    def last_stats(self) -> dict:
+        """dvn_groth16_last_stats_json of the last prove call on this key, parsed."""
+        return _stats_json(self.ctx, self.h)
+
+    def free(self):
+        if self.h:
+            self.ctx._chk(self.ctx.L.dvn_groth16_pk_free(self.ctx.h, self.h))
+            self.h = None
+
+
+def _stats_json(ctx, key_handle) -> dict:
+    import json
+    need = C.c_size_t()
+    ctx._chk(ctx.L.dvn_groth16_last_stats_json(key_handle, None, 0, C.byref(need)))
+    buf = C.create_string_buffer(need.value)
+    ctx._chk(ctx.L.dvn_groth16_last_stats_json(key_handle, buf, need.value, C.byref(need)))
+    return json.loads(buf.value.decode())
+
+
+def prove_multi(ctx: "Context", keys, witness: np.ndarray, r_mont, s_mont, solved=None, curve: str = "bn254") -> dict:
+    """One proof over all devices of a multi-device context.  keys: one key handle object (Groth16Key / ImportedKey /
+    LoadedKey) per device, keys[i] resident on ctx.device(i).  solved = (a, b, c): prove from the solver's output."""
+    a1 = {"bn254": 8, "bw6761": 24}.get(curve, 12)
+    a2 = a1 if curve == "bw6761" else 2 * a1
+    arr = (C.c_void_p * len(keys))(*[k.h for k in keys])
+    witness = np.ascontiguousarray(witness, dtype=np.uint64)
+    r_mont = np.ascontiguousarray(r_mont, dtype=np.uint64); s_mont = np.ascontiguousarray(s_mont, dtype=np.uint64)
+    out = np.zeros(2 * a1 + a2, dtype=np.uint64)
+    if solved is None:
+        assert curve == "bn254"
+        ctx._chk(ctx.L.dvn_groth16_prove_multi(ctx.h, arr, len(keys), _host(witness), _host(r_mont), _host(s_mont), _host(out)))
+    else:
+        a, b, c = (np.ascontiguousarray(x, dtype=np.uint64) for x in solved)
+        fn = ctx.L.dvn_groth16_prove_solved_multi if curve == "bn254" else getattr(ctx.L, f"dvn_{curve}_groth16_prove_solved_multi")
+        ctx._chk(fn(ctx.h, arr, len(keys), _host(witness), _host(a), _host(b), _host(c), a.shape[0], _host(r_mont), _host(s_mont), _host(out)))
+    return {"Ar": out[0:a1].copy(), "Bs": out[a1:a1 + a2].copy(), "Krs": out[a1 + a2:2 * a1 + a2].copy()}
+
+
+def gnark_pk_scan(data: bytes) -> dict:
+    """Host only: the section sizes of a gnark BN254 proving-key image (dvn_gnark_pk_scan)."""
+    L = load_library()
+    info = (C.c_uint64 * 11)()
+    rc = L.dvn_gnark_pk_scan(data, len(data), info)
+    if rc != 0:
+        raise DvnError(rc, L.dvn_last_error(None).decode())
+    names = ("log_n", "raw", "n_wires", "A", "B", "Z", "K", "B2", "n_commitments", "basis0", "domain_flag")
+    return dict(zip(names, (int(v) for v in info)))
+
+
+class LoadedKey:
+    """A proving key read from a gnark artifact file / image (dvn_groth16_pk_load_file / _load_bytes, BN254): proofs come from
+    the solver's output like ImportedKey's.  n_public and the committed private wires come from the constraint system gnark
+    loads next to the key."""
+
+    def __init__(self, ctx: "Context", source, n_public: int, committed_wires=(), sha256_hex: str | None = None):
+        self.ctx, self._a1, self._a2, self._prefix = ctx, 8, 16, "dvn_"
+        cw = np.ascontiguousarray(committed_wires, dtype=np.uint32)
+        cwp = C.c_void_p(cw.ctypes.data) if cw.size else None
+        h = C.c_void_p()
+        if isinstance(source, (bytes, bytearray)):
+            ctx._chk(ctx.L.dvn_groth16_pk_load_bytes(ctx.h, bytes(source), len(source), n_public, cwp, cw.size, C.byref(h)))
+        else:
+            ctx._chk(ctx.L.dvn_groth16_pk_load_file(ctx.h, str(source).encode(), sha256_hex.encode() if sha256_hex else None, n_public, cwp, cw.size, C.byref(h)))
+        self.h = h
+        ln = C.c_uint32(); sizes = (C.c_uint64 * 5)()
+        ctx.L.dvn_groth16_pk_info(h, C.byref(ln), sizes)
+        self.log_n = ln.value
+
+    prove_solved = None     # bound below to ImportedKey.prove_solved
+
+    def commitment_bases(self):
+        """(Basis, BasisExpSigma) Points handles owned by the key, or (None, None)."""
+        b, s = C.c_void_p(), C.c_void_p()
+        self.ctx._chk(self.ctx.L.dvn_groth16_pk_commitment_bases(self.h, C.byref(b), C.byref(s)))
+        return (Points(self.ctx, b, 1) if b.value else None, Points(self.ctx, s, 1) if s.value else None)
+
+    def last_stats(self) -> dict:
+        return _stats_json(self.ctx, self.h)
+
     def free(self):
         if self.h:
             self.ctx._chk(self.ctx.L.dvn_groth16_pk_free(self.ctx.h, self.h))
@@ -613,6 +753,10 @@ class ImportedKey:
         if self.h:
             self.ctx._chk(self.ctx.L.dvn_groth16_pk_free(self.ctx.h, self.h))
             self.h = None
+
+
+LoadedKey.prove_solved = ImportedKey.prove_solved
+ImportedKey.last_stats = lambda self: _stats_json(self.ctx, self.h)
 
 
 class Bls12377:
@@ -673,6 +817,13 @@ class Bls12377:
         self.ctx._chk(self._f("groth16_compute_h")(self.ctx.h, dom.handle, _host(a), _host(b), _host(c), a.shape[0], _host(out), 0))
         return out
 
+    def pedersen_commit(self, basis: Points, basis_exp_sigma: Points, values: np.ndarray):
+        """(commitment, pok) G1Affine images (12 uint64 each) of the BSB22 commitment hint on this curve."""
+        values = np.ascontiguousarray(values, dtype=np.uint64).reshape(-1, 4)
+        c, k = np.zeros(12, dtype=np.uint64), np.zeros(12, dtype=np.uint64)
+        self.ctx._chk(self._f("pedersen_commit")(self.ctx.h, basis.handle, basis_exp_sigma.handle, _host(values), values.shape[0], 0, _host(c), _host(k)))
+        return c, k
+
     def ntt(self, dom: Domain, data, inverse: bool, decimation: int, coset: bool = False):
         if isinstance(data, (int, np.integer)):
             self.ctx._chk(self._f("ntt")(self.ctx.h, dom.handle, C.c_void_p(int(data)), int(inverse), decimation, int(coset), NTT_DATA_ON_DEVICE))
@@ -725,6 +876,13 @@ class Bw6761:
         out = np.zeros(36, dtype=np.uint64)
         self.ctx._chk(self.L.dvn_bw6761_msm(self.ctx.h, pts.handle, off, ns, sp, fl, _host(out)))
         return out
+
+    def pedersen_commit(self, basis: Points, basis_exp_sigma: Points, values: np.ndarray):
+        """(commitment, pok) G1Affine images (24 uint64 each): the aggregator circuit's BSB22 commitment hint."""
+        values = np.ascontiguousarray(values, dtype=np.uint64).reshape(-1, 6)
+        c, k = np.zeros(24, dtype=np.uint64), np.zeros(24, dtype=np.uint64)
+        self.ctx._chk(self.L.dvn_bw6761_pedersen_commit(self.ctx.h, basis.handle, basis_exp_sigma.handle, _host(values), values.shape[0], 0, _host(c), _host(k)))
+        return c, k
 
     def domain(self, log_n: int) -> Domain:
         p = C.c_void_p(); self.ctx._chk(self.L.dvn_bw6761_ntt_domain(self.ctx.h, log_n, C.byref(p)))

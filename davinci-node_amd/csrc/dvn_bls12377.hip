@@ -65,8 +65,8 @@ struct SuiteBls12377 {
     static int32_t msm_submit_g2(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, MsmLane** l) {
         return msm_submit<G2_377>(ctx, p, off, n, (const uint64_t*)s, DVN_MSM_SCALARS_ON_DEVICE, l);
     }
-    static int32_t msm_rows_submit_g1(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, u32 lo, u32 hi, MsmLane** l) { return msm_rows_submit<G1_377>(ctx, p, off, n, s, lo, hi, l); }
-    static int32_t msm_rows_submit_g2(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, u32 lo, u32 hi, MsmLane** l) { return msm_rows_submit<G2_377>(ctx, p, off, n, s, lo, hi, l); }
+    static int32_t msm_share_submit_g1(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, u32 rank, u32 world, MsmLane** l) { return msm_share_submit<G1_377>(ctx, p, off, n, s, rank, world, l); }
+    static int32_t msm_share_submit_g2(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, u32 rank, u32 world, MsmLane** l) { return msm_share_submit<G2_377>(ctx, p, off, n, s, rank, world, l); }
     static int32_t msm_collect_g1(dvn_ctx* ctx, MsmLane* l, H1::X* out) { return msm_collect<G1_377>(ctx, *l, out); }
     static int32_t msm_collect_g2(dvn_ctx* ctx, MsmLane* l, H2::X* out) { return msm_collect<G2_377>(ctx, *l, out); }
 };
@@ -89,4 +89,10 @@ extern "C" int32_t dvn_bls12377_groth16_prove_solved(dvn_ctx* ctx, dvn_groth16_p
 }
 extern "C" int32_t dvn_bls12377_groth16_pk_export_arrays(dvn_ctx* ctx, const dvn_groth16_pk* pk, int which, uint64_t* out, size_t cap_words, size_t* n_words) {
     return groth16_pk_export_arrays<SuiteBls12377>(ctx, pk, which, out, cap_words, n_words);
+}
+// Pedersen commitment + PoK on this curve: the BSB22 commitment hint of the voteverifier proofs (gnark-crypto
+// ecc/bls12-377/fr/pedersen ProvingKey.Commit / ProveKnowledge); the hash-to-field of the challenge stays in gnark.
+extern "C" int32_t dvn_bls12377_pedersen_commit(dvn_ctx* ctx, const dvn_points* basis, const dvn_points* basis_exp_sigma, const uint64_t* values_mont,
+                                                size_t n, uint32_t flags, uint64_t commitment_out[12], uint64_t pok_out[12]) {
+    return pedersen_commit<SuiteBls12377>(ctx, basis, basis_exp_sigma, values_mont, n, flags, commitment_out, pok_out);
 }

@@ -64,8 +64,8 @@ struct SuiteBls12381 {
     static int32_t msm_submit_g2(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, MsmLane** l) {
         return msm_submit<G2_381>(ctx, p, off, n, (const uint64_t*)s, DVN_MSM_SCALARS_ON_DEVICE, l);
     }
-    static int32_t msm_rows_submit_g1(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, u32 lo, u32 hi, MsmLane** l) { return msm_rows_submit<G1_381>(ctx, p, off, n, s, lo, hi, l); }
-    static int32_t msm_rows_submit_g2(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, u32 lo, u32 hi, MsmLane** l) { return msm_rows_submit<G2_381>(ctx, p, off, n, s, lo, hi, l); }
+    static int32_t msm_share_submit_g1(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, u32 rank, u32 world, MsmLane** l) { return msm_share_submit<G1_381>(ctx, p, off, n, s, rank, world, l); }
+    static int32_t msm_share_submit_g2(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, u32 rank, u32 world, MsmLane** l) { return msm_share_submit<G2_381>(ctx, p, off, n, s, rank, world, l); }
     static int32_t msm_collect_g1(dvn_ctx* ctx, MsmLane* l, H1::X* out) { return msm_collect<G1_381>(ctx, *l, out); }
     static int32_t msm_collect_g2(dvn_ctx* ctx, MsmLane* l, H2::X* out) { return msm_collect<G2_381>(ctx, *l, out); }
 };
@@ -92,3 +92,8 @@ extern "C" int32_t dvn_bls12381_groth16_pk_export_arrays(dvn_ctx* ctx, const dvn
 
 // ---- blob KZG (EIP-4844 / EIP-7594) on this curve: SURVEY.md row f3 ----------------------------------------------------
 #include "kzg_impl.h"
+// Pedersen commitment + PoK on this curve (gnark-crypto ecc/bls12-381/fr/pedersen ProvingKey.Commit / ProveKnowledge)
+extern "C" int32_t dvn_bls12381_pedersen_commit(dvn_ctx* ctx, const dvn_points* basis, const dvn_points* basis_exp_sigma, const uint64_t* values_mont,
+                                                size_t n, uint32_t flags, uint64_t commitment_out[12], uint64_t pok_out[12]) {
+    return pedersen_commit<SuiteBls12381>(ctx, basis, basis_exp_sigma, values_mont, n, flags, commitment_out, pok_out);
+}

@@ -103,8 +103,8 @@ struct SuiteBw6761 {
         return msm_submit<G_761>(ctx, p, off, n, (const uint64_t*)s, DVN_MSM_SCALARS_ON_DEVICE, l);
     }
     static int32_t msm_submit_g2(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, MsmLane** l) { return msm_submit_g1(ctx, p, off, n, s, l); }
-    static int32_t msm_rows_submit_g1(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, u32 lo, u32 hi, MsmLane** l) { return msm_rows_submit<G_761>(ctx, p, off, n, s, lo, hi, l); }
-    static int32_t msm_rows_submit_g2(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, u32 lo, u32 hi, MsmLane** l) { return msm_rows_submit<G_761>(ctx, p, off, n, s, lo, hi, l); }
+    static int32_t msm_share_submit_g1(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, u32 rank, u32 world, MsmLane** l) { return msm_share_submit<G_761>(ctx, p, off, n, s, rank, world, l); }
+    static int32_t msm_share_submit_g2(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, u32 rank, u32 world, MsmLane** l) { return msm_share_submit<G_761>(ctx, p, off, n, s, rank, world, l); }
     static int32_t msm_collect_g1(dvn_ctx* ctx, MsmLane* l, H1::X* out) { return msm_collect<G_761>(ctx, *l, out); }
     static int32_t msm_collect_g2(dvn_ctx* ctx, MsmLane* l, H2::X* out) { return msm_collect<G_761>(ctx, *l, out); }
 };
@@ -128,4 +128,18 @@ extern "C" int32_t dvn_bw6761_groth16_prove_solved(dvn_ctx* ctx, dvn_groth16_pk*
 }
 extern "C" int32_t dvn_bw6761_groth16_pk_export_arrays(dvn_ctx* ctx, const dvn_groth16_pk* pk, int which, uint64_t* out, size_t cap_words, size_t* n_words) {
     return groth16_pk_export_arrays<SuiteBw6761>(ctx, pk, which, out, cap_words, n_words);
+}
+// Pedersen commitment + PoK on this curve: the BSB22 commitment hint of the aggregator proof (gnark-crypto
+// ecc/bw6-761/fr/pedersen ProvingKey.Commit / ProveKnowledge); values are 6-word scalars.
+extern "C" int32_t dvn_bw6761_pedersen_commit(dvn_ctx* ctx, const dvn_points* basis, const dvn_points* basis_exp_sigma, const uint64_t* values_mont,
+                                              size_t n, uint32_t flags, uint64_t commitment_out[24], uint64_t pok_out[24]) {
+    return pedersen_commit<SuiteBw6761>(ctx, basis, basis_exp_sigma, values_mont, n, flags, commitment_out, pok_out);
+}
+// The aggregator proof over all devices of a multi-device context (see dvn_groth16_prove_solved_multi)
+extern "C" int32_t dvn_bw6761_groth16_prove_solved_multi(dvn_ctx* ctx, dvn_groth16_pk* const* keys, uint32_t nkeys, const uint64_t* w, const uint64_t* a,
+                                                         const uint64_t* b, const uint64_t* c, size_t len, const uint64_t* r_mont, const uint64_t* s_mont,
+                                                         uint64_t* proof_out) {
+    if (!a || !b || !c) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    const uint64_t* src[3] = {a, b, c};
+    return groth16_prove_multi<SuiteBw6761>(ctx, keys, nkeys, w, 0u, src, len, r_mont, s_mont, proof_out);
 }

@@ -1,9 +1,33 @@
 // libdvn_prover.so -- context lifetime, memory helpers, error plumbing (include/dvn_prover.h).
 // Host side of the boundary described in SURVEY.md §8(b); stands where gnark's icicle backend stands behind
 // /root/reference/prover/prover_gpu.go:24-61.
+#include <dlfcn.h>
 #include "dvn_internal.h"
 
 thread_local std::string tl_error;
+// ---- profiler markers (DVN_ROCTX=1): roctxRangePushA / roctxRangePop of whichever roctx library is installed -------------
+namespace {
+typedef int (*roctx_push_t)(const char*);
+typedef int (*roctx_pop_t)();
+struct Roctx {
+    roctx_push_t push = nullptr; roctx_pop_t pop = nullptr;
+    Roctx() {
+        const char* v = getenv("DVN_ROCTX");
+        if (!v || v[0] != '1') return;
+        for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            push = (roctx_push_t)dlsym(h, "roctxRangePushA"); pop = (roctx_pop_t)dlsym(h, "roctxRangePop");
+            if (push && pop) return;
+            push = nullptr; pop = nullptr;
+        }
+    }
+};
+Roctx& roctx() { static Roctx r; return r; }
+}  // namespace
+void dvn_roctx_push(const char* name) { Roctx& r = roctx(); if (r.push) (void)r.push(name); }
+void dvn_roctx_pop() { Roctx& r = roctx(); if (r.pop) (void)r.pop(); }
+
 int32_t fail(int32_t code, const char* fmt, ...) {
     char buf[512];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
@@ -17,14 +41,7 @@ int32_t fail(int32_t code, const char* fmt, ...) {
 extern "C" const char* dvn_version(void) { return "dvn-prover 0.1 (gfx950, BN254, 9x29-bit Montgomery)"; }
 extern "C" const char* dvn_last_error(const dvn_ctx*) { return tl_error.c_str(); }
 
-extern "C" int32_t dvn_init(const int* devs, int ndev, dvn_ctx** out) {
-    if (!out) return fail(DVN_ERR_INVALID_ARG, "out is NULL");
-    *out = nullptr;
-    int count = 0;
-    hipError_t e = hipGetDeviceCount(&count);
-    if (e != hipSuccess || count == 0) { (void)hipGetLastError(); return fail(DVN_ERR_NO_DEVICE, "no HIP device visible (%s)", hipGetErrorString(e)); }
-    int dev = (devs && ndev > 0) ? devs[0] : 0;
-    if (dev < 0 || dev >= count) return fail(DVN_ERR_NO_DEVICE, "device ordinal %d out of range (%d devices)", dev, count);
+static int32_t ctx_create(int dev, dvn_ctx** out) {
     dvn_ctx* ctx = new (std::nothrow) dvn_ctx();
     if (!ctx) return fail(DVN_ERR_OOM, "host allocation failed");
     ctx->device = dev;
@@ -40,14 +57,64 @@ extern "C" int32_t dvn_init(const int* devs, int ndev, dvn_ctx** out) {
         for (int i = 0; i < 4 && e2 == hipSuccess; ++i) e2 = hipEventCreate(&L.ev[i]);
         if (e2 == hipSuccess) e2 = hipHostMalloc((void**)&L.h_sums, DVN_HSUMS_WORDS * 4, hipHostMallocDefault);
     }
-    if (e2 != hipSuccess) { delete ctx; (void)hipGetLastError(); return fail(DVN_ERR_DEVICE, "context setup failed: %s", hipGetErrorString(e2)); }
+    if (e2 != hipSuccess) { delete ctx; (void)hipGetLastError(); return fail(DVN_ERR_DEVICE, "context setup failed on device %d: %s", dev, hipGetErrorString(e2)); }
     { int32_t rc = dvn_internal_static_scratch_init(ctx); if (rc != DVN_OK) { dvn_shutdown(ctx); return rc; } }
     *out = ctx;
     return DVN_OK;
 }
+// devs / ndev: every listed ordinal gets a context.  The handle returned serves devs[0]; the contexts of devs[1..] hang off it
+// (dvn_ctx_device) and are what the *_multi entry points spread one proof over.  An ordinal may repeat (two contexts sharing
+// one GPU): how a one-GPU box rehearses the multi-device path.
+extern "C" int32_t dvn_init(const int* devs, int ndev, dvn_ctx** out) {
+    if (!out) return fail(DVN_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (ndev < 0 || ndev > 64 || (ndev > 0 && !devs)) return fail(DVN_ERR_INVALID_ARG, "bad device list");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) { (void)hipGetLastError(); return fail(DVN_ERR_NO_DEVICE, "no HIP device visible (%s)", hipGetErrorString(e)); }
+    const int n = ndev > 0 ? ndev : 1;
+    for (int i = 0; i < n; ++i) {
+        const int dev = ndev > 0 ? devs[i] : 0;
+        if (dev < 0 || dev >= count) return fail(DVN_ERR_NO_DEVICE, "device ordinal %d out of range (%d devices)", dev, count);
+    }
+    dvn_ctx* primary = nullptr;
+    TRY(ctx_create(ndev > 0 ? devs[0] : 0, &primary));
+    for (int i = 1; i < n; ++i) {
+        dvn_ctx* sub = nullptr;
+        int32_t rc = ctx_create(devs[i], &sub);
+        if (rc != DVN_OK) { std::string keep = tl_error; dvn_shutdown(primary); tl_error = keep; return rc; }
+        sub->primary = primary;
+        primary->peers.push_back(sub);
+    }
+    (void)hipSetDevice(primary->device);
+    *out = primary;
+    return DVN_OK;
+}
+extern "C" int32_t dvn_ctx_device_count(const dvn_ctx* ctx) { return ctx ? 1 + (int32_t)ctx->peers.size() : 0; }
+extern "C" dvn_ctx* dvn_ctx_device(dvn_ctx* ctx, int32_t index) {
+    if (!ctx || index < 0 || index > (int32_t)ctx->peers.size()) { (void)fail(DVN_ERR_INVALID_ARG, "device index %d outside the context's %d devices", index, ctx ? 1 + (int)ctx->peers.size() : 0); return nullptr; }
+    return index == 0 ? ctx : ctx->peers[(size_t)index - 1];
+}
+extern "C" int32_t dvn_ctx_device_ordinal(const dvn_ctx* ctx) { return ctx ? ctx->device : -1; }
+extern "C" const char* dvn_error_string(int32_t code) {
+    switch (code) {
+        case DVN_OK: return "ok";
+        case DVN_ERR_INVALID_ARG: return "invalid argument";
+        case DVN_ERR_DEVICE: return "HIP call failed";
+        case DVN_ERR_NO_DEVICE: return "no usable gfx950 device";
+        case DVN_ERR_OOM: return "out of memory";
+        case DVN_ERR_UNSUPPORTED: return "unsupported";
+        case DVN_ERR_INJECTED: return "injected failure (DVN_FORCE_FAIL)";
+        default: return "unknown error code";
+    }
+}
+int32_t dvn_internal_key_cache_clear(dvn_ctx* ctx);      // dvn_artifacts.hip
 extern "C" void dvn_shutdown(dvn_ctx* ctx) {
     if (!ctx) return;
+    for (dvn_ctx* sub : ctx->peers) { sub->primary = nullptr; dvn_shutdown(sub); }
+    ctx->peers.clear();
     (void)hipSetDevice(ctx->device);
+    (void)dvn_internal_key_cache_clear(ctx);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
     for (int l = 0; l < DVN_LANES; ++l) {

@@ -3,27 +3,8 @@
 // commitment of gnark's BSB22 hint.  The MSMs and computeH of this suite are the ones compiled in dvn_msm_g1.hip,
 // dvn_msm_g2.hip and dvn_ntt.hip (cross-TU calls: the kernels are not instantiated a second time here).
 #include "groth16_impl.h"
+#include "suite_bn254.h"
 
-
-struct SuiteBn254 {
-    typedef FrCfg FrC;
-    typedef G1 G1T;
-    typedef G2 G2T;
-    typedef dvn_host::HG1 H1;
-    typedef dvn_host::HG2 H2;
-    static constexpr int SUITE = 0;
-    static const u32* r_words() { return FR_MOD_W; }
-    static G1::A g1_gen() { return g1_generator(); }
-    static G2::A g2_gen() { return g2_generator(); }
-    static int32_t domain_create(dvn_ctx* ctx, u32 log_n, dvn_domain** out) { return dvn_ntt_domain(ctx, log_n, out); }
-    static int32_t compute_h(dvn_ctx* ctx, const dvn_domain* dom, u32* a, u32* b, u32* c) { return dvn_internal_compute_h_dev(ctx, dom, a, b, c); }
-    static int32_t msm_submit_g1(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, MsmLane** l) { return dvn_internal_msm_submit_g1(ctx, p, off, n, s, l); }
-    static int32_t msm_submit_g2(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, MsmLane** l) { return dvn_internal_msm_submit_g2(ctx, p, off, n, s, l); }
-    static int32_t msm_rows_submit_g1(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, u32 lo, u32 hi, MsmLane** l) { return dvn_internal_msm_rows_submit_g1(ctx, p, off, n, s, lo, hi, l); }
-    static int32_t msm_rows_submit_g2(dvn_ctx* ctx, const dvn_points* p, size_t off, size_t n, const u32* s, u32 lo, u32 hi, MsmLane** l) { return dvn_internal_msm_rows_submit_g2(ctx, p, off, n, s, lo, hi, l); }
-    static int32_t msm_collect_g1(dvn_ctx* ctx, MsmLane* l, H1::X* out) { return dvn_internal_msm_collect_g1(ctx, l, out); }
-    static int32_t msm_collect_g2(dvn_ctx* ctx, MsmLane* l, H2::X* out) { return dvn_internal_msm_collect_g2(ctx, l, out); }
-};
 
 extern "C" int32_t dvn_r1cs_synthetic(uint64_t seed, uint32_t n_constraints, uint32_t n_public, dvn_r1cs** out) {
     return r1cs_synthetic<SuiteBn254>(seed, n_constraints, n_public, out);
@@ -46,6 +27,23 @@ extern "C" int32_t dvn_groth16_prove_combine(const dvn_groth16_pk* pk, const uin
     return groth16_prove_combine<SuiteBn254>(pk, partials, world, r_mont, s_mont, proof_out);
 }
 
+// One proof over all devices of a multi-device context (dvn_init(devs, ndev > 1)); keys[i] = the key on dvn_ctx_device(ctx, i)
+extern "C" int32_t dvn_groth16_prove_multi(dvn_ctx* ctx, dvn_groth16_pk* const* keys, uint32_t nkeys, const uint64_t* witness,
+                                           const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32]) {
+    return groth16_prove_multi<SuiteBn254>(ctx, keys, nkeys, witness, 0u, nullptr, 0, r_mont, s_mont, proof_out);
+}
+extern "C" int32_t dvn_groth16_prove_solved_multi(dvn_ctx* ctx, dvn_groth16_pk* const* keys, uint32_t nkeys, const uint64_t* w, const uint64_t* a,
+                                                  const uint64_t* b, const uint64_t* c, size_t len, const uint64_t r_mont[4], const uint64_t s_mont[4],
+                                                  uint64_t proof_out[32]) {
+    if (!a || !b || !c) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    const uint64_t* src[3] = {a, b, c};
+    return groth16_prove_multi<SuiteBn254>(ctx, keys, nkeys, w, 0u, src, len, r_mont, s_mont, proof_out);
+}
+extern "C" int32_t dvn_groth16_last_stats_json(const dvn_groth16_pk* pk, char* buf, size_t cap, size_t* needed) {
+    if (!pk) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    return groth16_stats_json(pk, buf, cap, needed);
+}
+
 // ---- curve-independent handles ------------------------------------------------------------------------------------
 // gnark's ecc.ID numbering of the prover package mirror: 1 BN254, 2 BLS12_377, 3 BLS12_381, 4 BW6_761
 extern "C" int32_t dvn_r1cs_curve(const dvn_r1cs* cs) { return !cs ? 0 : cs->suite == 0 ? 1 : cs->suite == 1 ? 2 : cs->suite == 3 ? 3 : cs->suite == 2 ? 4 : 0; }
@@ -66,6 +64,7 @@ extern "C" void dvn_r1cs_free(dvn_r1cs* cs) { delete cs; }
 extern "C" int32_t dvn_groth16_pk_free(dvn_ctx* ctx, dvn_groth16_pk* pk) {
     TRY(enter(ctx));
     if (!pk) return DVN_OK;
+    if (pk->cached) return DVN_OK;             // resident in the artifact cache until dvn_shutdown
     dvn_points* ps[] = {pk->A, pk->B, pk->K, pk->Z, pk->B2, pk->Basis, pk->BasisSigma};
     for (dvn_points* p : ps) if (p) (void)dvn_points_free(ctx, p);
     if (pk->dom) (void)dvn_ntt_domain_free(ctx, pk->dom);
@@ -157,32 +156,7 @@ extern "C" int32_t dvn_groth16_proof_abi_encode(const uint64_t proof[32], const 
 extern "C" int32_t dvn_pedersen_commit(dvn_ctx* ctx, const dvn_points* basis, const dvn_points* basis_exp_sigma,
                                        const uint64_t* values_mont, size_t n, uint32_t flags,
                                        uint64_t commitment_out[8], uint64_t pok_out[8]) {
-    TRY(enter(ctx));
-    if (!basis || !basis_exp_sigma || (!values_mont && n) || !commitment_out || !pok_out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
-    if (basis->curve != 1 || basis_exp_sigma->curve != 1) return fail(DVN_ERR_INVALID_ARG, "bases must be G1 point sets");
-    if (n > basis->n || n > basis_exp_sigma->n) return fail(DVN_ERR_INVALID_ARG, "len(values) exceeds the basis");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    u32* d_vals = nullptr;
-    const u32* vals = (const u32*)values_mont;
-    if (!(flags & 1) && n) {               // host values: one upload shared by both MSMs
-        HIP_TRY(hipMalloc((void**)&d_vals, n * 32));
-        hipError_t e = hipMemcpy(d_vals, values_mont, n * 32, hipMemcpyHostToDevice);
-        if (e != hipSuccess) { (void)hipFree(d_vals); (void)hipGetLastError(); return fail(DVN_ERR_DEVICE, "upload failed: %s", hipGetErrorString(e)); }
-        vals = d_vals;
-    }
-    typedef dvn_host::HG1 H1;
-    MsmLane *la = nullptr, *lb = nullptr;
-    H1::X c, k;
-    int32_t rc = dvn_internal_msm_submit_g1(ctx, basis, 0, n, vals, &la);
-    if (rc == DVN_OK) rc = dvn_internal_msm_submit_g1(ctx, basis_exp_sigma, 0, n, vals, &lb);
-    if (rc == DVN_OK) rc = dvn_internal_msm_collect_g1(ctx, la, &c); else if (la) { H1::X t; (void)dvn_internal_msm_collect_g1(ctx, la, &t); }
-    if (rc == DVN_OK) rc = dvn_internal_msm_collect_g1(ctx, lb, &k);
-    if (d_vals) (void)hipFree(d_vals);
-    if (rc != DVN_OK) return rc;
-    uint64_t j[12];
-    H1::write_jac(c, j); memcpy(commitment_out, j, 64); if (H1::is_inf(c)) memset(commitment_out, 0, 64);
-    H1::write_jac(k, j); memcpy(pok_out, j, 64); if (H1::is_inf(k)) memset(pok_out, 0, 64);
-    return DVN_OK;
+    return pedersen_commit<SuiteBn254>(ctx, basis, basis_exp_sigma, values_mont, n, flags, commitment_out, pok_out);
 }
 
 

@@ -33,7 +33,7 @@ struct MsmLane {
     void* ext_ws = nullptr; size_t ext_bytes = 0;
     u32* h_sums = nullptr;        // pinned host buffer for the per-window sums
     bool busy = false;
-    int curve = 0; bool expanded = false; u32 c = 0, nwin = 0, W = 0; u32 seq = 0;
+    int curve = 0, suite = 0; bool expanded = false; u32 c = 0, nwin = 0, W = 0; u32 seq = 0;
     float ms[2] = {0.f, 0.f};
 };
 constexpr int DVN_LANES = 4;
@@ -52,6 +52,12 @@ struct dvn_ctx {
     bool force_fail = false;
     // this device's copy of the library's static scratch array (resolved once at dvn_init with hipGetSymbolAddress)
     void* static_ws = nullptr; size_t static_ws_bytes = 0;
+    // dvn_init(devs, ndev) with ndev > 1: one sub-context per further device ordinal (devs[1..]); this context serves devs[0].
+    // A sub-context is a complete context of its own (streams, lanes, workspaces on its device), owned by the primary.
+    std::vector<dvn_ctx*> peers;
+    dvn_ctx* primary = nullptr;          // set in sub-contexts
+    // sha256 -> proving key loaded from an artifact file (dvn_groth16_pk_load_file); keys stay owned by the cache
+    std::vector<std::pair<std::string, struct dvn_groth16_pk*>> key_cache;
 };
 struct dvn_points {
     int suite = 0;            // 0 = BN254, 1 = BLS12-377
@@ -93,6 +99,17 @@ struct dvn_domain {
 };
 
 int32_t fail(int32_t code, const char* fmt, ...);
+
+// rocprofv3 / roctracer ranges around the stages of a proof (H2D, gathers, each MSM, computeH and its transforms, collect):
+// resolved with dlopen at first use and only when DVN_ROCTX=1, so the library has no link-time dependency on a profiler
+// and the markers cost nothing otherwise.
+void dvn_roctx_push(const char* name);
+void dvn_roctx_pop();
+struct RoctxRange {
+    explicit RoctxRange(const char* name) { dvn_roctx_push(name); }
+    ~RoctxRange() { dvn_roctx_pop(); }
+    RoctxRange(const RoctxRange&) = delete;
+};
 #define HIP_TRY(expr)                                                                                         \
     do {                                                                                                      \
         hipError_t _e = (expr);                                                                               \
@@ -201,8 +218,8 @@ int32_t dvn_internal_msm_submit_g2(dvn_ctx* ctx, const dvn_points* pts, size_t o
 int32_t dvn_internal_msm_collect_g1(dvn_ctx* ctx, MsmLane* lane, dvn_host::HG1::X* out);
 int32_t dvn_internal_msm_collect_g2(dvn_ctx* ctx, MsmLane* lane, dvn_host::HG2::X* out);
 // rows [lo, hi) of an expanded set: one partial result per call (sharded Groth16)
-int32_t dvn_internal_msm_rows_submit_g1(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, u32 lo, u32 hi, MsmLane** lane);
-int32_t dvn_internal_msm_rows_submit_g2(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, u32 lo, u32 hi, MsmLane** lane);
+int32_t dvn_internal_msm_share_submit_g1(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, u32 rank, u32 world, MsmLane** lane);
+int32_t dvn_internal_msm_share_submit_g2(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, u32 rank, u32 world, MsmLane** lane);
 // computeH on three device vectors of n = 2^log_n elements (already zero padded); result left in da (dvn_ntt.hip)
 int32_t dvn_internal_compute_h_dev(dvn_ctx* ctx, const dvn_domain* dom, u32* da, u32* db, u32* dc);
 uint32_t dvn_internal_domain_log_n(const dvn_domain* dom);

@@ -109,7 +109,7 @@ extern "C" int32_t dvn_msm_plan_points(const dvn_points* pts, size_t n, uint32_t
 static int32_t windows_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
                               uint32_t win_lo, uint32_t win_hi, MsmLane** out) {
     if (!pts || (!scalars && n)) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
-    if (pts->curve != 1) return fail(DVN_ERR_INVALID_ARG, "point set is not G1");
+    if (pts->curve != 1 || pts->suite != 0) return fail(DVN_ERR_INVALID_ARG, "point set is not BN254 G1");
     if (off > pts->n || n > pts->n - off) return fail(DVN_ERR_INVALID_ARG, "len(points) != len(scalars)");
     const bool expanded = use_expanded(pts, n);
     u32 c, nwin;
@@ -117,7 +117,7 @@ static int32_t windows_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, s
     if (win_lo > win_hi || win_hi > nwin) return fail(DVN_ERR_INVALID_ARG, "window range [%u, %u) outside [0, %u)", win_lo, win_hi, nwin);
     MsmLane* L = nullptr;
     TRY(lane_acquire(ctx, &L));
-    L->curve = 1; L->expanded = expanded; L->c = c; L->nwin = nwin; L->W = win_hi - win_lo;
+    L->curve = 1; L->suite = 0; L->expanded = expanded; L->c = c; L->nwin = nwin; L->W = win_hi - win_lo;
     int32_t rc = DVN_OK;
     if (n && L->W) {
         rc = expanded ? msm_expanded<G1>(ctx, *L, pts, off, n, scalars, flags, win_lo, win_hi)
@@ -158,7 +158,7 @@ extern "C" int32_t dvn_msm_g1_windows_collect(dvn_ctx* ctx, int32_t ticket, uint
     if (!window_sums || ticket < 1 || ticket > DVN_LANES) return fail(DVN_ERR_INVALID_ARG, "bad ticket");
     std::lock_guard<std::mutex> lk(ctx->mu);
     MsmLane& L = ctx->lane[ticket - 1];
-    if (!L.busy || L.curve != 1) return fail(DVN_ERR_INVALID_ARG, "ticket %d is not an outstanding window-sharded G1 MSM", ticket);
+    if (!L.busy || L.curve != 1 || L.suite != 0) return fail(DVN_ERR_INVALID_ARG, "ticket %d is not an outstanding window-sharded BN254 G1 MSM", ticket);
     return windows_collect(ctx, L, window_sums);
 }
 extern "C" int32_t dvn_msm_g1_windows(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
@@ -187,6 +187,42 @@ extern "C" int32_t dvn_msm_combine_g1(dvn_ctx* ctx, const uint64_t* window_sums,
     return DVN_OK;
 }
 
+// ---- one MSM shared between the GPUs of a node by entry count ---------------------------------------------------------------
+// Rank `rank` of `world` computes ITS SHARE of sum s_i P_i and returns it as a G1Jac image; the shares of all ranks add up to
+// the MSM (dvn_msm_g1_sum, host only).  For an expanded point set the share is an equal range of the nexp * n (row, point)
+// entries: perfectly balanced for any world size, where whole rows are not (13 rows over 8 ranks).  The exchange between
+// ranks is one all-gather of 96 bytes per rank (RCCL has no elliptic-curve reduction operator; the sum runs on the host).
+// Scalars must already be in device memory.
+extern "C" int32_t dvn_msm_g1_share_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* d_scalars_mont,
+                                           uint32_t flags, uint32_t rank, uint32_t world, int32_t* ticket) {
+    TRY(enter(ctx));
+    if (!pts || !ticket || (!d_scalars_mont && n)) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    if (pts->curve != 1 || pts->suite != 0) return fail(DVN_ERR_INVALID_ARG, "point set is not BN254 G1");
+    if (!(flags & DVN_MSM_SCALARS_ON_DEVICE)) return fail(DVN_ERR_INVALID_ARG, "a shared MSM takes device scalars (DVN_MSM_SCALARS_ON_DEVICE)");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    MsmLane* L = nullptr;
+    TRY(msm_share_submit<G1>(ctx, pts, off, n, (const u32*)d_scalars_mont, rank, world, &L));
+    *ticket = (int32_t)(L - ctx->lane) + 1;
+    return DVN_OK;
+}
+extern "C" int32_t dvn_msm_g1_share_collect(dvn_ctx* ctx, int32_t ticket, uint64_t partial_jac[12]) { return msm_collect_api<G1>(ctx, 1, ticket, partial_jac); }
+extern "C" int32_t dvn_msm_g1_sum(const uint64_t* jacs, uint32_t count, uint64_t out_jac[12]) {
+    typedef dvn_host::HG1 HG;
+    if ((!jacs && count) || !out_jac) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    HG::X acc = HG::infinity();
+    for (uint32_t k = 0; k < count; ++k) {
+        const u32* w = (const u32*)(jacs + (size_t)k * 12);
+        bool z = true;
+        for (int i = 0; i < 8; ++i) z = z && w[16 + i] == 0;                    // Z == 0: infinity
+        if (z) continue;
+        u32 img[G1::AW];
+        G1::store_affine_internal(G1::affine_from_ext(w), img);                 // Z = 1 images (what the library emits)
+        acc = HG::add(acc, HG::load_device_affine(img));
+    }
+    HG::write_jac(acc, out_jac);
+    return DVN_OK;
+}
+
 extern "C" size_t dvn_points_len(const dvn_points* pts) { return pts ? pts->n : 0; }
 
 extern "C" int32_t dvn_points_free(dvn_ctx* ctx, dvn_points* pts) {
@@ -202,6 +238,7 @@ extern "C" int32_t dvn_points_free(dvn_ctx* ctx, dvn_points* pts) {
 extern "C" int32_t dvn_points_download(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, uint64_t* xy) {
     TRY(enter(ctx));
     if (!pts || (!xy && n)) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    if (pts->suite != 0) return fail(DVN_ERR_INVALID_ARG, "point set is not a BN254 set (use the download call of its curve)");
     if (off > pts->n || n > pts->n - off) return fail(DVN_ERR_INVALID_ARG, "range [%zu, %zu) outside point set of %zu", off, off + n, pts->n);
     std::lock_guard<std::mutex> lk(ctx->mu);
     return pts->curve == 1 ? points_download<G1>(ctx, pts, off, n, xy) : dvn_internal_points_download_g2(ctx, pts, off, n, xy);
@@ -242,7 +279,7 @@ int32_t dvn_internal_msm_submit_g1(dvn_ctx* ctx, const dvn_points* pts, size_t o
     return msm_submit<G1>(ctx, pts, off, n, (const uint64_t*)d_scalars, DVN_MSM_SCALARS_ON_DEVICE, lane);
 }
 int32_t dvn_internal_msm_collect_g1(dvn_ctx* ctx, MsmLane* lane, dvn_host::HG1::X* out) { return msm_collect<G1>(ctx, *lane, out); }
-int32_t dvn_internal_msm_rows_submit_g1(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, u32 lo, u32 hi, MsmLane** lane) {
+int32_t dvn_internal_msm_share_submit_g1(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, u32 rank, u32 world, MsmLane** lane) {
     if (pts->curve != 1) return fail(DVN_ERR_INVALID_ARG, "point set is not G1");
-    return msm_rows_submit<G1>(ctx, pts, off, n, d_scalars, lo, hi, lane);
+    return msm_share_submit<G1>(ctx, pts, off, n, d_scalars, rank, world, lane);
 }

@@ -29,7 +29,7 @@ int32_t dvn_internal_msm_submit_g2(dvn_ctx* ctx, const dvn_points* pts, size_t o
     return msm_submit<G2>(ctx, pts, off, n, (const uint64_t*)d_scalars, DVN_MSM_SCALARS_ON_DEVICE, lane);
 }
 int32_t dvn_internal_msm_collect_g2(dvn_ctx* ctx, MsmLane* lane, dvn_host::HG2::X* out) { return msm_collect<G2>(ctx, *lane, out); }
-int32_t dvn_internal_msm_rows_submit_g2(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, u32 lo, u32 hi, MsmLane** lane) {
+int32_t dvn_internal_msm_share_submit_g2(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, u32 rank, u32 world, MsmLane** lane) {
     if (pts->curve != 2) return fail(DVN_ERR_INVALID_ARG, "point set is not G2");
-    return msm_rows_submit<G2>(ctx, pts, off, n, d_scalars, lo, hi, lane);
+    return msm_share_submit<G2>(ctx, pts, off, n, d_scalars, rank, world, lane);
 }

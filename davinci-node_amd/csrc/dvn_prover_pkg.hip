@@ -12,6 +12,7 @@
 // The CPU prover is NOT part of this library: in the node it is gnark's groth16.Prove.  CPUProver therefore calls a
 // backend registered by the embedder (dvn_prover_set_cpu_backend); with none registered it returns an error -- it never
 // silently computes on the CPU.
+#include <atomic>
 #include <chrono>
 #include "dvn_internal.h"
 
@@ -27,23 +28,33 @@ typedef dvn_prover_request Request;
 typedef dvn_prover_func ProverFunc;
 typedef dvn_cpu_backend CpuBackend;
 
-bool UseGPUProver = false;
+// Package-level state, as in prover/config.go: read on every Prove (from any thread / goroutine), written by SetProver, the
+// test hooks and init().  The flag is atomic; the two (function, user) pairs are replaced under a mutex and copied out under it,
+// so a Prove racing a SetProver sees either the old pair or the new one, never a mix.
+std::atomic<bool> UseGPUProver{false};
+static std::mutex hooks_mu;
 static ProverFunc custom_prover = nullptr; static void* custom_user = nullptr;
 static CpuBackend cpu_backend = nullptr; static void* cpu_user = nullptr;
 static thread_local int last_backend = 0;   // 1 = GPU, 2 = CPU, 3 = custom
 
-void init_from_env() {
+static bool env_wants_gpu() {
     const char* v = getenv("GPU_PROVER");
-    UseGPUProver = v && (!strcmp(v, "true") || !strcmp(v, "y") || !strcmp(v, "1") || !strcmp(v, "yes"));
-    fprintf(stderr, "[prover] GPU prover usage enabled=%s\n", UseGPUProver ? "true" : "false");
+    return v && (!strcmp(v, "true") || !strcmp(v, "y") || !strcmp(v, "1") || !strcmp(v, "yes"));
 }
-struct EnvInit { EnvInit() { const char* v = getenv("GPU_PROVER"); UseGPUProver = v && (!strcmp(v, "true") || !strcmp(v, "y") || !strcmp(v, "1") || !strcmp(v, "yes")); } };
+void init_from_env() {
+    UseGPUProver.store(env_wants_gpu());
+    fprintf(stderr, "[prover] GPU prover usage enabled=%s\n", UseGPUProver.load() ? "true" : "false");
+}
+struct EnvInit { EnvInit() { UseGPUProver.store(env_wants_gpu()); } };
 static EnvInit env_init;                     // Go's package init()
 
 int32_t CPUProverWithWitness(const Request* q) {
     last_backend = 2;
-    if (!cpu_backend) return fail(DVN_ERR_UNSUPPORTED, "CPU prover not linked: register gnark's groth16.Prove with dvn_prover_set_cpu_backend");
-    return cpu_backend(q->curve, q->witness, q->r, q->s, q->proof, cpu_user);
+    CpuBackend fn; void* user;
+    { std::lock_guard<std::mutex> lk(hooks_mu); fn = cpu_backend; user = cpu_user; }
+    if (!fn) return fail(DVN_ERR_UNSUPPORTED, "CPU prover not linked: register gnark's groth16.Prove with dvn_prover_set_cpu_backend");
+    // the reference hands the CPU prover (ccs, cpuReadyProvingKey(pk), witness) (prover_gpu.go:126-131): so does this call
+    return fn(q->curve, q->ccs, q->pk, q->witness, q->r, q->s, q->proof, user);
 }
 int32_t callGPUProver(const Request* q) {
     switch (q->curve) {
@@ -69,7 +80,7 @@ int32_t CPUProver(const Request* q) { return CPUProverWithWitness(q); }
 int32_t GPUProver(const Request* q) { return GPUProverWithWitness(q); }
 
 int32_t ProveWithWitness(const Request* q) {
-    if (UseGPUProver) {
+    if (UseGPUProver.load()) {
         int32_t rc = GPUProverWithWitness(q);
         if (rc != DVN_OK) {
             printf("GPU proving failed (%s), falling back to CPU\n", tl_error.c_str());
@@ -82,35 +93,38 @@ int32_t ProveWithWitness(const Request* q) {
 }
 int32_t defaultProver(const Request* q) { return ProveWithWitness(q); }
 int32_t Prove(const Request* q) {
-    if (custom_prover) { last_backend = 3; return custom_prover(q, custom_user); }
+    ProverFunc fn; void* user;
+    { std::lock_guard<std::mutex> lk(hooks_mu); fn = custom_prover; user = custom_user; }
+    if (fn) { last_backend = 3; return fn(q, user); }
     return defaultProver(q);
 }
-void SetProver(ProverFunc p, void* user) { custom_prover = p; custom_user = user; }
+void SetProver(ProverFunc p, void* user) { std::lock_guard<std::mutex> lk(hooks_mu); custom_prover = p; custom_user = user; }
+void SetCpuBackend(CpuBackend b, void* user) { std::lock_guard<std::mutex> lk(hooks_mu); cpu_backend = b; cpu_user = user; }
 
 int32_t Setup(dvn_ctx* ctx, const dvn_r1cs* ccs, uint64_t seed, dvn_groth16_pk** pk) {
     uint32_t nc = 0; dvn_r1cs_info(ccs, nullptr, nullptr, &nc);
-    fprintf(stderr, "[prover] generating circuit keys gpu=%s constraints=%u\n", UseGPUProver ? "true" : "false", nc);
+    fprintf(stderr, "[prover] generating circuit keys gpu=%s constraints=%u\n", UseGPUProver.load() ? "true" : "false", nc);
     auto t0 = std::chrono::steady_clock::now();
     const int32_t cid = dvn_r1cs_curve(ccs);
     int32_t rc = cid == BLS12_377 ? dvn_bls12377_groth16_setup(ctx, ccs, seed, pk) : cid == BLS12_381 ? dvn_bls12381_groth16_setup(ctx, ccs, seed, pk)
                : cid == BW6_761 ? dvn_bw6761_groth16_setup(ctx, ccs, seed, pk) : dvn_groth16_setup(ctx, ccs, seed, pk);
     if (rc == DVN_OK) {
         double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        fprintf(stderr, "[prover] circuit keys setup done took=%.3fs gpu=%s constraints=%u\n", s, UseGPUProver ? "true" : "false", nc);
+        fprintf(stderr, "[prover] circuit keys setup done took=%.3fs gpu=%s constraints=%u\n", s, UseGPUProver.load() ? "true" : "false", nc);
     }
     return rc;
 }
 }  // namespace prover
 
 // ---- C-ABI of the package mirror -----------------------------------------------------------------------------
-extern "C" int32_t dvn_prover_use_gpu(void) { return prover::UseGPUProver ? 1 : 0; }
-extern "C" void dvn_prover_set_use_gpu(int32_t on) { prover::UseGPUProver = on != 0; }
+extern "C" int32_t dvn_prover_use_gpu(void) { return prover::UseGPUProver.load() ? 1 : 0; }
+extern "C" void dvn_prover_set_use_gpu(int32_t on) { prover::UseGPUProver.store(on != 0); }
 extern "C" void dvn_prover_reload_env(void) { prover::init_from_env(); }
 extern "C" void dvn_prover_set_prover(prover::ProverFunc p, void* user) { prover::SetProver(p, user); }
-extern "C" void dvn_prover_set_cpu_backend(prover::CpuBackend b, void* user) { prover::cpu_backend = b; prover::cpu_user = user; }
+extern "C" void dvn_prover_set_cpu_backend(prover::CpuBackend b, void* user) { prover::SetCpuBackend(b, user); }
 extern "C" int32_t dvn_prover_last_backend(void) { return prover::last_backend; }
 extern "C" int32_t dvn_prover_prove(dvn_ctx* ctx, int32_t curve, const dvn_r1cs* ccs, dvn_groth16_pk* pk, const uint64_t* witness,
-                                    const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32]) {
+                                    const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out) {
     prover::Request q{curve, ctx, ccs, pk, witness, r_mont, s_mont, proof_out};
     return prover::Prove(&q);
 }

@@ -16,6 +16,7 @@
 #pragma once
 #include <algorithm>
 #include <future>
+#include <thread>
 #include "dvn_internal.h"
 #include "msm_kernels.h"
 #include "ntt_kernels.h"
@@ -59,6 +60,14 @@ struct dvn_groth16_pk {
     u32 *d_ptr[3] = {nullptr, nullptr, nullptr}, *d_idx[3] = {nullptr, nullptr, nullptr}, *d_coef[3] = {nullptr, nullptr, nullptr};
     u32 *d_w = nullptr, *d_abc = nullptr, *d_wA = nullptr, *d_wB = nullptr;   // per-proof buffers, allocated once
     float ms_h = 0, ms_msm = 0, ms_total = 0;
+    // per-proof statistics of the last prove call on this key (dvn_groth16_last_stats_json): device ms of each MSM as its lane
+    // measured it (A, B1, K, Z, B2), pairs it consumed, host-to-device bytes of the call, rank / world of a shared proof
+    float msm_ms[5] = {0, 0, 0, 0, 0};
+    size_t msm_pairs[5] = {0, 0, 0, 0, 0};
+    size_t h2d_bytes = 0;
+    u32 last_rank = 0, last_world = 1;
+    int device = -1;                    // HIP ordinal the key's arrays live on
+    u32 scalar_bytes = 0, g1_bytes = 0, g2_bytes = 0;     // image sizes of the key's curve (statistics)
     // BSB22 commitment (n_committed = 0: none): K covers the wires [k_first, m); Basis / BasisSigma the committed ones
     size_t k_first = 0;
     u32 commit_wire = 0, n_committed = 0, tail = 0;
@@ -68,6 +77,7 @@ struct dvn_groth16_pk {
     u32 *d_idxK = nullptr, *d_wK = nullptr;
     size_t nK = 0;
     bool imported = false;
+    bool cached = false;                // owned by the context's sha256-keyed key cache: dvn_groth16_pk_free leaves it alone
     // verifying key as gnark affine Montgomery images (uint64 words): alpha (G1) | beta | gamma | delta (G2) | IC[n_public] (G1:
     // CONSTANT, PUB_i of the Solidity verifier) | Pedersen G | Pedersen GSigmaNeg (G2; only with a commitment)
     std::vector<uint64_t> vk_words;
@@ -318,7 +328,8 @@ template <class SU> static int32_t groth16_setup(dvn_ctx* ctx, const dvn_r1cs* c
     const size_t n = (size_t)1 << log_n, m = cs->n_wires;
     dvn_groth16_pk* pk = new (std::nothrow) dvn_groth16_pk();
     if (!pk) return fail(DVN_ERR_OOM, "host allocation failed");
-    pk->suite = SU::SUITE;
+    pk->suite = SU::SUITE; pk->device = ctx->device;
+    pk->scalar_bytes = S::EW * 4; pk->g1_bytes = G1::AW * 4; pk->g2_bytes = G2::AW * 4;
     pk->log_n = log_n; pk->n = n; pk->m = m; pk->n_public = cs->n_public; pk->n_constraints = cs->n_constraints;
     int32_t rc = SU::domain_create(ctx, log_n, &pk->dom);
     if (rc) { delete pk; return rc; }
@@ -503,53 +514,72 @@ template <class SU> static int32_t groth16_device(dvn_ctx* ctx, dvn_groth16_pk* 
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
     auto submit_g1 = [&](const dvn_points* p, size_t cnt, const u32* sc, MsmLane** l) -> int32_t {
         if (world == 1) return SU::msm_submit_g1(ctx, p, 0, cnt, sc, l);
-        return SU::msm_rows_submit_g1(ctx, p, 0, cnt, sc, rank * p->nexp / world, (rank + 1) * p->nexp / world, l);
+        return SU::msm_share_submit_g1(ctx, p, 0, cnt, sc, rank, world, l);
     };
     auto submit_g2 = [&](const dvn_points* p, size_t cnt, const u32* sc, MsmLane** l) -> int32_t {
         if (world == 1) return SU::msm_submit_g2(ctx, p, 0, cnt, sc, l);
-        return SU::msm_rows_submit_g2(ctx, p, 0, cnt, sc, rank * p->nexp / world, (rank + 1) * p->nexp / world, l);
+        return SU::msm_share_submit_g2(ctx, p, 0, cnt, sc, rank, world, l);
     };
+    // every lane this proof acquires is tracked here: if a later submit, computeH or a collect fails, the lanes still in
+    // flight are drained and released, so one failed proof never leaves the context with busy lanes
+    MsmLane* lanes[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // B2, A, B1, K, Z
+    pk->h2d_bytes = 0; pk->last_rank = rank; pk->last_world = world;
     auto body = [&]() -> int32_t {
+        MsmLane *&l2 = lanes[0], *&lA = lanes[1], *&lB = lanes[2], *&lK = lanes[3], *&lZ = lanes[4];
         HIP_TRY(hipEventRecord(e0, st));
-        if (!(flags & 2))      // flags & 2: the (completed) witness already sits in pk->d_w (committed proofs)
+        if (!(flags & 2)) {    // flags & 2: the (completed) witness already sits in pk->d_w (committed proofs)
+            RoctxRange rr("dvn:witness_copy");
             HIP_TRY(hipMemcpyAsync(pk->d_w, witness, m * EB, (flags & 1) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+            if (!(flags & 1)) pk->h2d_bytes += m * EB;
+        }
         // (4) filter the wire vector by InfinityA / InfinityB
-        if (pk->nA) k_gather_fr<S::EW><<<(unsigned)((pk->nA + 255) / 256), 256, 0, st>>>(pk->d_w, pk->d_idxA, pk->d_wA, pk->nA);
-        if (pk->nB) k_gather_fr<S::EW><<<(unsigned)((pk->nB + 255) / 256), 256, 0, st>>>(pk->d_w, pk->d_idxB, pk->d_wB, pk->nB);
-        HIP_TRY(hipGetLastError());
+        {
+            RoctxRange rr("dvn:wire_filter");
+            if (pk->nA) k_gather_fr<S::EW><<<(unsigned)((pk->nA + 255) / 256), 256, 0, st>>>(pk->d_w, pk->d_idxA, pk->d_wA, pk->nA);
+            if (pk->nB) k_gather_fr<S::EW><<<(unsigned)((pk->nB + 255) / 256), 256, 0, st>>>(pk->d_w, pk->d_idxB, pk->d_wB, pk->nB);
+            HIP_TRY(hipGetLastError());
+        }
         // (6) the four MSMs that need only the wire values go to four lanes at once (a lane waits for what the main stream
         // holds at submit time, i.e. the gathers): their sorts and latency-bound bucket reductions overlap each other ...
-        MsmLane *l2 = nullptr, *lA = nullptr, *lB = nullptr, *lK = nullptr, *lZ = nullptr;
-        TRY(submit_g2(pk->B2, pk->nB, pk->d_wB, &l2));
-        TRY(submit_g1(pk->A, pk->nA, pk->d_wA, &lA));
-        TRY(submit_g1(pk->B, pk->nB, pk->d_wB, &lB));
-        if (pk->d_idxK) {                                  // imported key: K's wires are an index list (private minus committed)
-            if (pk->nK) k_gather_fr<S::EW><<<(unsigned)((pk->nK + 255) / 256), 256, 0, st>>>(pk->d_w, pk->d_idxK, pk->d_wK, pk->nK);
-            HIP_TRY(hipGetLastError());
-            TRY(submit_g1(pk->K, pk->nK, pk->d_wK, &lK));
-        } else TRY(submit_g1(pk->K, m - pk->k_first, pk->d_w + pk->k_first * EW, &lK));
+        { RoctxRange rr("dvn:msm_submit:G2.B"); TRY(submit_g2(pk->B2, pk->nB, pk->d_wB, &l2)); }
+        { RoctxRange rr("dvn:msm_submit:G1.A"); TRY(submit_g1(pk->A, pk->nA, pk->d_wA, &lA)); }
+        { RoctxRange rr("dvn:msm_submit:G1.B"); TRY(submit_g1(pk->B, pk->nB, pk->d_wB, &lB)); }
+        size_t nK = 0;
+        {
+            RoctxRange rr("dvn:msm_submit:G1.K");
+            if (pk->d_idxK) {                                  // imported key: K's wires are an index list (private minus committed)
+                if (pk->nK) k_gather_fr<S::EW><<<(unsigned)((pk->nK + 255) / 256), 256, 0, st>>>(pk->d_w, pk->d_idxK, pk->d_wK, pk->nK);
+                HIP_TRY(hipGetLastError());
+                nK = pk->nK;
+                TRY(submit_g1(pk->K, pk->nK, pk->d_wK, &lK));
+            } else { nK = m - pk->k_first; TRY(submit_g1(pk->K, nK, pk->d_w + pk->k_first * EW, &lK)); }
+        }
         // ... while the main stream runs (1) the "solve" a = A w, b = B w, c = C w (zero padded to the domain size) and
         // (3) h = computeH(a, b, c), which stays on the device as the scalar vector of the Z MSM
         if (abc_host) {                                    // the solver's (a, b, c) from host memory: their upload runs under the wire-only MSMs
+            RoctxRange rr("dvn:abc_copy");
             HIP_TRY(hipMemsetAsync(pk->d_abc, 0, 3 * n * EB, st));
             for (int q = 0; q < 3; ++q)
                 if (abc_len) HIP_TRY(hipMemcpyAsync(pk->d_abc + (size_t)q * n * EW, abc_host[q], abc_len * EB, hipMemcpyHostToDevice, st));
+            pk->h2d_bytes += 3 * abc_len * EB;
         } else if (!(flags & 4)) {                         // flags & 4: (a, b, c) already sit zero-padded in pk->d_abc
+            RoctxRange rr("dvn:r1cs_matvec");
             HIP_TRY(hipMemsetAsync(pk->d_abc, 0, 3 * n * EB, st));
             for (int q = 0; q < 3; ++q)
                 k_r1cs_matvec<S><<<(unsigned)((pk->n_constraints + 127) / 128), 128, 0, st>>>(pk->d_ptr[q], pk->d_idx[q], pk->d_coef[q], pk->d_w,
                                                                                           pk->d_abc + (size_t)q * n * EW, (u32)pk->n_constraints);
             HIP_TRY(hipGetLastError());
         }
-        TRY(SU::compute_h(ctx, pk->dom, pk->d_abc, pk->d_abc + n * EW, pk->d_abc + 2 * n * EW));
+        { RoctxRange rr("dvn:compute_h"); TRY(SU::compute_h(ctx, pk->dom, pk->d_abc, pk->d_abc + n * EW, pk->d_abc + 2 * n * EW)); }
         HIP_TRY(hipEventRecord(e1, st));
         // Z takes the first lane that frees up: its submit makes the lane wait for computeH
-        TRY(SU::msm_collect_g1(ctx, lA, &out->mA));
-        TRY(submit_g1(pk->Z, n - 1, pk->d_abc, &lZ));                                // h[:n-1] against Z[:n-1]
-        TRY(SU::msm_collect_g1(ctx, lB, &out->mB));
-        TRY(SU::msm_collect_g1(ctx, lK, &out->mK));
-        TRY(SU::msm_collect_g1(ctx, lZ, &out->mZ));
-        TRY(SU::msm_collect_g2(ctx, l2, &out->mB2));
+        RoctxRange rc_("dvn:msm_collect");
+        TRY(SU::msm_collect_g1(ctx, lA, &out->mA)); pk->msm_ms[0] = lA->ms[0]; pk->msm_pairs[0] = pk->nA; lA = nullptr;
+        { RoctxRange rr("dvn:msm_submit:G1.Z"); TRY(submit_g1(pk->Z, n - 1, pk->d_abc, &lZ)); }                // h[:n-1] against Z[:n-1]
+        TRY(SU::msm_collect_g1(ctx, lB, &out->mB)); pk->msm_ms[1] = lB->ms[0]; pk->msm_pairs[1] = pk->nB; lB = nullptr;
+        TRY(SU::msm_collect_g1(ctx, lK, &out->mK)); pk->msm_ms[2] = lK->ms[0]; pk->msm_pairs[2] = nK; lK = nullptr;
+        TRY(SU::msm_collect_g1(ctx, lZ, &out->mZ)); pk->msm_ms[3] = lZ->ms[0]; pk->msm_pairs[3] = n - 1; lZ = nullptr;
+        TRY(SU::msm_collect_g2(ctx, l2, &out->mB2)); pk->msm_ms[4] = l2->ms[0]; pk->msm_pairs[4] = pk->nB; l2 = nullptr;
         HIP_TRY(hipEventRecord(e2, st));
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipEventElapsedTime(&pk->ms_h, e0, e1));
@@ -558,6 +588,14 @@ template <class SU> static int32_t groth16_device(dvn_ctx* ctx, dvn_groth16_pk* 
         return DVN_OK;
     };
     int32_t rc = body();
+    if (rc != DVN_OK) {
+        std::string keep = tl_error;
+        (void)hipStreamSynchronize(st);                   // the caller's host buffers may still be the source of queued copies
+        for (MsmLane* L : lanes)
+            if (L && L->busy) { (void)hipStreamSynchronize(L->stream); L->busy = false; }
+        (void)hipGetLastError();
+        tl_error = keep;
+    }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
     return rc;
 }
@@ -615,6 +653,7 @@ template <class SU> static int32_t groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* p
     if (!pk || !witness || !r_mont || !s_mont || !proof_out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (pk->suite != SU::SUITE) return fail(DVN_ERR_INVALID_ARG, "proving key belongs to another curve");
     if (pk->imported) return fail(DVN_ERR_INVALID_ARG, "imported key: it has no constraint system, prove from the solver's output (prove_solved)");
+    if (pk->n_committed) return fail(DVN_ERR_INVALID_ARG, "the key carries a BSB22 commitment: the plain prover would leave the commitment wire unset and the proof could not verify; use dvn_groth16_prove_committed");
     const HostKey<SU>& hk = *(const HostKey<SU>*)pk->hk;
     std::lock_guard<std::mutex> lk(ctx->mu);
     Blind<SU> bl(hk, r_mont, s_mont);
@@ -652,7 +691,8 @@ template <class SU> static int32_t groth16_pk_import(dvn_ctx* ctx, const Groth16
     for (size_t i = 0; i < d.nK; ++i) if (d.idxK[i] >= d.m) return fail(DVN_ERR_INVALID_ARG, "idxK[%zu] outside the wire vector", i);
     dvn_groth16_pk* pk = new (std::nothrow) dvn_groth16_pk();
     if (!pk) return fail(DVN_ERR_OOM, "host allocation failed");
-    pk->suite = SU::SUITE; pk->imported = true;
+    pk->suite = SU::SUITE; pk->imported = true; pk->device = ctx->device;
+    pk->scalar_bytes = S::EW * 4; pk->g1_bytes = G1::AW * 4; pk->g2_bytes = G2::AW * 4;
     pk->log_n = d.log_n; pk->n = n; pk->m = d.m; pk->n_public = 0; pk->n_constraints = n; pk->nA = d.nA; pk->nB = d.nB; pk->nK = d.nK; pk->k_first = d.m - d.nK;
     auto body = [&]() -> int32_t {
         TRY(SU::domain_create(ctx, d.log_n, &pk->dom));
@@ -742,6 +782,9 @@ template <class SU> static int32_t groth16_prove_solved(dvn_ctx* ctx, dvn_groth1
     if (!pk || !w || !a || !b || !c || !r_mont || !s_mont || !proof_out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (pk->suite != SU::SUITE) return fail(DVN_ERR_INVALID_ARG, "proving key belongs to another curve");
     if (len > pk->n) return fail(DVN_ERR_INVALID_ARG, "len = %zu exceeds the domain size %zu", len, pk->n);
+    // a Setup-built key with a commitment knows its committed wires (K skips them by position) but this entry point takes the
+    // solver's finished (w, a, b, c): only imported keys, whose K index list already leaves the committed wires out, qualify
+    if (pk->n_committed && !pk->imported) return fail(DVN_ERR_INVALID_ARG, "the key carries a BSB22 commitment: use dvn_groth16_prove_committed");
     const HostKey<SU>& hk = *(const HostKey<SU>*)pk->hk;
     std::lock_guard<std::mutex> lk(ctx->mu);
     Blind<SU> bl(hk, r_mont, s_mont);
@@ -769,6 +812,7 @@ template <class SU> static int32_t groth16_prove_shard(dvn_ctx* ctx, dvn_groth16
     if (pk->suite != SU::SUITE) return fail(DVN_ERR_INVALID_ARG, "proving key belongs to another curve");
     if (world < 1 || world > 64 || rank >= world) return fail(DVN_ERR_INVALID_ARG, "rank %u outside world %u", rank, world);
     if (pk->imported) return fail(DVN_ERR_INVALID_ARG, "imported key: it has no constraint system");
+    if (pk->n_committed) return fail(DVN_ERR_INVALID_ARG, "the key carries a BSB22 commitment: the plain prover would leave the commitment wire unset");
     std::lock_guard<std::mutex> lk(ctx->mu);
     MsmResults<SU> R;
     TRY(groth16_device<SU>(ctx, pk, witness, flags & 1u, rank, world, &R));
@@ -810,5 +854,126 @@ template <class SU> static int32_t groth16_prove_combine(const dvn_groth16_pk* p
         R.mZ = H1::add(R.mZ, rd1(p + 3 * J1)); R.mB2 = H2::add(R.mB2, rd2(p + 4 * J1));
     }
     groth16_assemble<SU>(hk, R, bl, proof_out);
+    return DVN_OK;
+}
+
+// ---- one proof spread over the devices of a multi-device context (dvn_init(devs, ndev > 1)) -------------------------------------
+// keys[i] is the SAME proving key resident on device i (dvn_ctx_device(ctx, i)): built by Setup or imported there.  One host
+// thread per device runs that device's share of the five MSMs (groth16_device with rank i of ndev: replicated wire filtering /
+// computeH, the device's entry range of every expanded key set); the partial results come back through pinned host memory and
+// are added on the host (five group additions per device), then blinded and assembled as usual.  No collective is involved:
+// one process sees all partial results, and the whole exchange is 5 points per device.  The statetransition proof is the
+// node's serialisation point (/root/reference/sequencer/statetransition.go:80): this is the call that shortens it.
+template <class SU> static int32_t groth16_prove_multi(dvn_ctx* ctx, dvn_groth16_pk* const* keys, uint32_t nkeys, const uint64_t* witness, uint32_t flags,
+                                                       const uint64_t* const* abc_host, size_t abc_len,
+                                                       const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out) {
+    typedef typename SU::H1 H1;
+    typedef typename SU::H2 H2;
+    if (!ctx) return fail(DVN_ERR_INVALID_ARG, "ctx is NULL");
+    if (!keys || !witness || !r_mont || !s_mont || !proof_out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    const uint32_t ndev = 1 + (uint32_t)ctx->peers.size();
+    if (nkeys != ndev) return fail(DVN_ERR_INVALID_ARG, "%u keys for a context of %u devices: one key per device", nkeys, ndev);
+    if (flags & 1u) return fail(DVN_ERR_INVALID_ARG, "multi-device proving takes the witness from host memory (every device uploads its own copy)");
+    for (uint32_t i = 0; i < ndev; ++i) {
+        dvn_groth16_pk* pk = keys[i];
+        dvn_ctx* ci = i == 0 ? ctx : ctx->peers[i - 1];
+        if (!pk) return fail(DVN_ERR_INVALID_ARG, "keys[%u] is NULL", i);
+        if (pk->suite != SU::SUITE) return fail(DVN_ERR_INVALID_ARG, "keys[%u] belongs to another curve", i);
+        if (pk->device != ci->device) return fail(DVN_ERR_INVALID_ARG, "keys[%u] lives on device %d, the context's device %u is %d", i, pk->device, i, ci->device);
+        if (pk->m != keys[0]->m || pk->n != keys[0]->n) return fail(DVN_ERR_INVALID_ARG, "keys[%u] is not the same key as keys[0]", i);
+        if (!abc_host && pk->imported) return fail(DVN_ERR_INVALID_ARG, "imported key: prove from the solver's output (prove_solved_multi)");
+        if (pk->n_committed && !pk->imported) return fail(DVN_ERR_INVALID_ARG, "the key carries a BSB22 commitment: not supported by the multi-device prover");
+        if (abc_host && abc_len > pk->n) return fail(DVN_ERR_INVALID_ARG, "len = %zu exceeds the domain size %zu", abc_len, pk->n);
+    }
+    const HostKey<SU>& hk = *(const HostKey<SU>*)keys[0]->hk;
+    Blind<SU> bl(hk, r_mont, s_mont);
+    std::vector<MsmResults<SU>> parts(ndev);
+    std::vector<int32_t> rcs(ndev, DVN_OK);
+    std::vector<std::string> errs(ndev);
+    std::vector<std::thread> threads;
+    for (uint32_t i = 0; i < ndev; ++i) {
+        threads.emplace_back([&, i]() {
+            dvn_ctx* ci = i == 0 ? ctx : ctx->peers[i - 1];
+            int32_t rc = enter(ci);                             // hipSetDevice on this thread
+            if (rc == DVN_OK) {
+                std::lock_guard<std::mutex> lk(ci->mu);
+                RoctxRange rr("dvn:device_share");
+                rc = groth16_device<SU>(ci, keys[i], witness, 0u, i, ndev, &parts[i], abc_host, abc_len);
+            }
+            rcs[i] = rc;
+            if (rc != DVN_OK) errs[i] = tl_error;
+        });
+    }
+    for (auto& t : threads) t.join();
+    for (uint32_t i = 0; i < ndev; ++i)
+        if (rcs[i] != DVN_OK) return fail(rcs[i], "device share %u of %u failed: %s", i, ndev, errs[i].c_str());
+    RoctxRange rr("dvn:host_combine");
+    MsmResults<SU> R{H1::infinity(), H1::infinity(), H1::infinity(), H1::infinity(), H2::infinity()};
+    for (uint32_t i = 0; i < ndev; ++i) {
+        R.mA = H1::add(R.mA, parts[i].mA); R.mB = H1::add(R.mB, parts[i].mB); R.mK = H1::add(R.mK, parts[i].mK);
+        R.mZ = H1::add(R.mZ, parts[i].mZ); R.mB2 = H2::add(R.mB2, parts[i].mB2);
+    }
+    groth16_assemble<SU>(hk, R, bl, proof_out);
+    return DVN_OK;
+}
+
+// ---- per-proof statistics as JSON (what the reference logs with log.DebugTime around a proof,
+// /root/reference/circuits/artifacts.go:572-577, plus what a device prover can add: stage times, bytes moved, achieved rate) ---
+static inline int32_t groth16_stats_json(const dvn_groth16_pk* pk, char* buf, size_t cap, size_t* needed) {
+    const size_t sb = pk->scalar_bytes, a1 = pk->g1_bytes, a2 = pk->g2_bytes;
+    static const char* names[5] = {"G1.A", "G1.B", "G1.K", "G1.Z", "G2.B"};
+    // algorithmic bytes: one scalar + one affine point per MSM pair, 7 transforms of (read + write) and the 4-vector pointwise
+    // pass of computeH
+    double alg = 0;
+    for (int i = 0; i < 5; ++i) alg += (double)pk->msm_pairs[i] * (double)(sb + (i == 4 ? a2 : a1));
+    alg += 7.0 * 2.0 * (double)sb * (double)pk->n + 4.0 * (double)sb * (double)pk->n;
+    std::string o = "{";
+    char t[256];
+    snprintf(t, sizeof(t), "\"suite\": %d, \"log_n\": %u, \"wires\": %zu, \"rank\": %u, \"world\": %u, ", pk->suite, pk->log_n, pk->m, pk->last_rank, pk->last_world); o += t;
+    snprintf(t, sizeof(t), "\"device_ms\": {\"until_h_ready\": %.4f, \"after_h\": %.4f, \"total\": %.4f}, ", pk->ms_h, pk->ms_msm, pk->ms_total); o += t;
+    o += "\"msm\": {";
+    for (int i = 0; i < 5; ++i) { snprintf(t, sizeof(t), "%s\"%s\": {\"pairs\": %zu, \"device_ms\": %.4f}", i ? ", " : "", names[i], pk->msm_pairs[i], pk->msm_ms[i]); o += t; }
+    snprintf(t, sizeof(t), "}, \"bytes\": {\"host_to_device\": %zu, \"algorithmic\": %.0f}, \"achieved_GBps\": %.3f}", pk->h2d_bytes, alg,
+             pk->ms_total > 0 ? alg / (pk->ms_total * 1e-3) / 1e9 : 0.0); o += t;
+    if (needed) *needed = o.size() + 1;
+    if (!buf) return DVN_OK;
+    if (cap < o.size() + 1) return fail(DVN_ERR_INVALID_ARG, "buffer holds %zu bytes, the statistics need %zu", cap, o.size() + 1);
+    memcpy(buf, o.c_str(), o.size() + 1);
+    return DVN_OK;
+}
+
+// ---- Pedersen commitment + proof of knowledge on any curve (gnark-crypto ecc/<curve>/fr/pedersen ProvingKey.Commit /
+// ProveKnowledge behind the BSB22 commitment hint of groth16.Prove): two G1 MSMs over the committed wire values, in flight
+// together.  values: n scalar images (host, or device with flags & 1).  Outputs: G1Affine images of the curve.
+template <class SU> static int32_t pedersen_commit(dvn_ctx* ctx, const dvn_points* basis, const dvn_points* basis_exp_sigma,
+                                                   const uint64_t* values_mont, size_t n, uint32_t flags, uint64_t* commitment_out, uint64_t* pok_out) {
+    typedef typename SU::FrC S;
+    typedef typename SU::H1 H1;
+    constexpr size_t SB = (size_t)S::EW * 4, A1 = SU::G1T::AW / 2;
+    TRY(enter(ctx));
+    if (!basis || !basis_exp_sigma || (!values_mont && n) || !commitment_out || !pok_out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    if (basis->curve != 1 || basis_exp_sigma->curve != 1 || basis->suite != SU::SUITE || basis_exp_sigma->suite != SU::SUITE)
+        return fail(DVN_ERR_INVALID_ARG, "bases must be G1 point sets of this curve");
+    if (n > basis->n || n > basis_exp_sigma->n) return fail(DVN_ERR_INVALID_ARG, "len(values) exceeds the basis");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    u32* d_vals = nullptr;
+    const u32* vals = (const u32*)values_mont;
+    if (!(flags & 1) && n) {               // host values: one upload shared by both MSMs
+        HIP_TRY(hipMalloc((void**)&d_vals, n * SB));
+        hipError_t e = hipMemcpy(d_vals, values_mont, n * SB, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(d_vals); (void)hipGetLastError(); return fail(DVN_ERR_DEVICE, "upload failed: %s", hipGetErrorString(e)); }
+        vals = d_vals;
+    }
+    MsmLane *la = nullptr, *lb = nullptr;
+    typename H1::X c, k;
+    int32_t rc = SU::msm_submit_g1(ctx, basis, 0, n, vals, &la);
+    if (rc == DVN_OK) rc = SU::msm_submit_g1(ctx, basis_exp_sigma, 0, n, vals, &lb);
+    if (rc == DVN_OK) rc = SU::msm_collect_g1(ctx, la, &c); else if (la) { typename H1::X t; (void)SU::msm_collect_g1(ctx, la, &t); }
+    if (rc == DVN_OK) rc = SU::msm_collect_g1(ctx, lb, &k); else if (lb && lb->busy) { typename H1::X t; (void)SU::msm_collect_g1(ctx, lb, &t); }
+    if (d_vals) (void)hipFree(d_vals);
+    if (rc != DVN_OK) return rc;
+    uint64_t j[3 * A1 / 2 + 1];
+    H1::write_jac(c, j); memcpy(commitment_out, j, A1 * 8); if (H1::is_inf(c)) memset(commitment_out, 0, A1 * 8);
+    H1::write_jac(k, j); memcpy(pok_out, j, A1 * 8); if (H1::is_inf(k)) memset(pok_out, 0, A1 * 8);
     return DVN_OK;
 }

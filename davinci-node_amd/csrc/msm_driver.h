@@ -174,12 +174,16 @@ static inline u32 giant_threshold() {       // DVN_MSM_GIANT=<segments> override
     return v;
 }
 // LDS limits of the staged sort kernels (dynamic LDS above the 64 KiB default needs the attribute once per kernel)
-template <class D> static int32_t sort_attrs() {
-    static bool done = false;
-    if (!done) {
+// (a function attribute is a property of the function ON ONE DEVICE: once per device, with that device current)
+template <class D> static int32_t sort_attrs(int device) {
+    static std::mutex mu;
+    static bool done[64] = {false};
+    std::lock_guard<std::mutex> lk(mu);
+    if (device < 0 || device >= 64) return fail(DVN_ERR_INVALID_ARG, "device ordinal %d out of range", device);
+    if (!done[device]) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_s1_scatter<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         HIP_TRY(hipFuncSetAttribute((const void*)k_s2_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        done = true;
+        done[device] = true;
     }
     return DVN_OK;
 }
@@ -283,7 +287,7 @@ static int32_t msm_windows_staged(dvn_ctx* ctx, MsmLane& L, const dvn_points* pt
     static const bool dbg = getenv("DVN_DEBUG_SYNC") != nullptr;
 #define DBG_SYNC(name) do { if (dbg) { hipError_t _e = hipStreamSynchronize(st); fprintf(stderr, "[dvn] %s: %s\n", name, hipGetErrorString(_e)); fflush(stderr); if (_e != hipSuccess) return fail(DVN_ERR_DEVICE, "%s: %s", name, hipGetErrorString(_e)); } } while (0)
     if (dbg) { fprintf(stderr, "[dvn] msm(staged) n=%zu c=%u W=%u nb=%u lob=%u lb=%u seg=%u nseg=%u tpw=%u ws=%zu\n", n, c, W, nb, lob, lb, seg, nseg, tpw, cs.off); fflush(stderr); }
-    TRY(sort_attrs<int16_t>());
+    TRY(sort_attrs<int16_t>(ctx->device));
     HIP_TRY(hipEventRecord(L.ev[0], st));
     TRY(lane_zero(L, totals, 16, st));
     if (batched) k_digits16_batched<typename ScalarOf<Cv>::S><<<(unsigned)((n_src * batch + 255) / 256), 256, 0, st>>>(d_scalars, n_src, batch, c, win_hi, digits);
@@ -361,7 +365,7 @@ static inline bool use_expanded(const dvn_points* pts, size_t n) {
 }
 template <class Cv>
 static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
-                            u32 win_lo, u32 win_hi) {
+                            u32 win_lo, u32 win_hi, u64 flat_lo = 0, u64 flat_hi = ~(u64)0) {
     typedef typename PairedOf<Cv>::type KC;
     constexpr u32 LPP = Lanes<KC>::LPP;
     const u32 c = pts->expand_c, W = win_hi - win_lo;
@@ -425,10 +429,10 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
     hipStream_t st = L.stream;
     static const bool dbg = getenv("DVN_DEBUG_SYNC") != nullptr;
     if (dbg) { fprintf(stderr, "[dvn] msm(expanded) n=%zu c=%u W=%u nb=%u lob=%u lb=%u seg=%u nseg=%u tpw=%u ws=%zu\n", n, c, W, nb, lob, lb, seg, nseg, tpw, cs.off); fflush(stderr); }
-    TRY(sort_attrs<int>());
+    TRY(sort_attrs<int>(ctx->device));
     HIP_TRY(hipEventRecord(L.ev[0], st));
     TRY(lane_zero(L, totals, 16, st));
-    k_digits32<typename ScalarOf<Cv>::S><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_scalars, n, c, win_lo, win_hi, digits);
+    k_digits32<typename ScalarOf<Cv>::S><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_scalars, n, c, win_lo, win_hi, digits, flat_lo, flat_hi);
     DBG_SYNC("k_digits32");
     k_s1_hist<int><<<W * tpw, 1024, (size_t)lb * 4, st>>>(digits, n, tpw, lob, lb, hist1);
     DBG_SYNC("k_s1_hist");
@@ -593,7 +597,7 @@ static int32_t msm_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_
     MsmLane* L = nullptr;
     TRY(lane_acquire(ctx, &L));
     if (static_scratch) { L->ext_ws = ctx->static_ws; L->ext_bytes = ctx->static_ws_bytes; }
-    L->curve = pts->curve; L->W = 0;
+    L->curve = pts->curve; L->suite = pts->suite; L->W = 0;
     int32_t rc = DVN_OK;
     if (n == 0) { L->nwin = 0; }
     else if (use_expanded(pts, n)) {
@@ -608,18 +612,31 @@ static int32_t msm_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_
     *lane_out = L;
     return DVN_OK;
 }
-// rows [row_lo, row_hi) of an EXPANDED set (device scalars): ONE partial result, window weights included; the partial
-// results of disjoint row ranges add up to the MSM (this is what a rank of the sharded Groth16 prover computes)
+// Share `rank` of `world` of one MSM (device scalars): ONE partial result; the partial results of all ranks add up to the MSM
+// (this is what one GPU of a sharded prover computes).  An expanded set (row w = 2^(c w) P) is shared by ENTRY COUNT: its
+// nexp * n (row, point) entries, in row-major order, are cut into `world` equal ranges -- 13 rows over 8 GPUs are 1.625 rows
+// each, not 2 / 2 / 2 / 2 / 2 / 1 / 1 / 1 -- a rank runs the rows its range touches with the entries outside the range
+// masked to zero digits.  A set too small to be expanded (< 2^15 points: microseconds of work) is computed whole by rank 0,
+// the other ranks contribute the point at infinity.
 template <class Cv>
-static int32_t msm_rows_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, u32 row_lo, u32 row_hi, MsmLane** lane_out) {
+static int32_t msm_share_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, u32 rank, u32 world, MsmLane** lane_out) {
     if (off > pts->n || n > pts->n - off) return fail(DVN_ERR_INVALID_ARG, "len(points) != len(scalars): range [%zu, %zu) outside point set of %zu", off, off + n, pts->n);
-    if (n && !use_expanded(pts, n)) return fail(DVN_ERR_UNSUPPORTED, "row-sharded MSM needs an expanded point set (n >= 2^15 points, most of the set)");
-    if (row_lo > row_hi || (n && row_hi > pts->nexp)) return fail(DVN_ERR_INVALID_ARG, "row range [%u, %u) outside [0, %u)", row_lo, row_hi, pts->nexp);
+    if (world == 0 || rank >= world) return fail(DVN_ERR_INVALID_ARG, "rank %u outside world %u", rank, world);
+    if (n && !use_expanded(pts, n)) {
+        if (rank == 0) return msm_submit<Cv>(ctx, pts, off, n, (const uint64_t*)d_scalars, DVN_MSM_SCALARS_ON_DEVICE, lane_out);
+        n = 0;
+    }
     MsmLane* L = nullptr;
     TRY(lane_acquire(ctx, &L));
-    L->curve = pts->curve; L->W = 0; L->expanded = true; L->c = 0;
-    L->nwin = (n && row_hi > row_lo) ? 1 : 0;
-    int32_t rc = L->nwin ? msm_expanded<Cv>(ctx, *L, pts, off, n, (const uint64_t*)d_scalars, DVN_MSM_SCALARS_ON_DEVICE, row_lo, row_hi) : DVN_OK;
+    L->curve = pts->curve; L->suite = pts->suite; L->W = 0; L->expanded = true; L->c = 0;
+    const u64 flat_total = (u64)pts->nexp * n;
+    const u64 flat_lo = flat_total * rank / world, flat_hi = flat_total * (rank + 1) / world;
+    L->nwin = (n && flat_hi > flat_lo) ? 1 : 0;
+    int32_t rc = DVN_OK;
+    if (L->nwin) {
+        const u32 row_lo = (u32)(flat_lo / n), row_hi = (u32)((flat_hi + n - 1) / n);
+        rc = msm_expanded<Cv>(ctx, *L, pts, off, n, (const uint64_t*)d_scalars, DVN_MSM_SCALARS_ON_DEVICE, row_lo, row_hi, flat_lo, flat_hi);
+    }
     if (rc != DVN_OK) { (void)hipStreamSynchronize(L->stream); L->busy = false; return rc; }
     *lane_out = L;
     return DVN_OK;
@@ -635,7 +652,7 @@ static int32_t msm_batched_submit(dvn_ctx* ctx, const dvn_points* pts, size_t of
     MsmLane* L = nullptr;
     TRY(lane_acquire(ctx, &L));
     const u32 nwin = ScalarOf<Cv>::S::BITS / c + 1;
-    L->curve = pts->curve; L->W = 0; L->expanded = false; L->c = c; L->nwin = nwin;
+    L->curve = pts->curve; L->suite = pts->suite; L->W = 0; L->expanded = false; L->c = c; L->nwin = nwin;
     int32_t rc = msm_windows_staged<Cv>(ctx, *L, pts, off, n, (const uint64_t*)d_scalars, DVN_MSM_SCALARS_ON_DEVICE, c, 0, nwin, batch, d_out, row_table);
     if (rc != DVN_OK) { (void)hipStreamSynchronize(L->stream); L->busy = false; return rc; }
     *lane_out = L;
@@ -693,7 +710,7 @@ template <class Cv>
 static int32_t msm_submit_api(dvn_ctx* ctx, const dvn_points* pts, int curve, size_t off, size_t n, const uint64_t* scalars, uint32_t flags, int32_t* ticket) {
     TRY(enter(ctx));
     if (!pts || !ticket || (!scalars && n)) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
-    if (pts->curve != curve) return fail(DVN_ERR_INVALID_ARG, "point set is G%d, call is G%d", pts->curve, curve);
+    if (pts->curve != curve || pts->suite != SuiteOf<Cv>::value) return fail(DVN_ERR_INVALID_ARG, "point set is G%d of suite %d, call is G%d of suite %d", pts->curve, pts->suite, curve, SuiteOf<Cv>::value);
     std::lock_guard<std::mutex> lk(ctx->mu);
     MsmLane* L = nullptr;
     TRY(msm_submit<Cv>(ctx, pts, off, n, scalars, flags, &L));
@@ -706,7 +723,7 @@ static int32_t msm_collect_api(dvn_ctx* ctx, int curve, int32_t ticket, uint64_t
     if (!out_jac || ticket < 1 || ticket > DVN_LANES) return fail(DVN_ERR_INVALID_ARG, "bad ticket");
     std::lock_guard<std::mutex> lk(ctx->mu);
     MsmLane& L = ctx->lane[ticket - 1];
-    if (!L.busy || L.curve != curve) return fail(DVN_ERR_INVALID_ARG, "ticket %d is not an outstanding G%d MSM", ticket, curve);
+    if (!L.busy || L.curve != curve || L.suite != SuiteOf<Cv>::value) return fail(DVN_ERR_INVALID_ARG, "ticket %d is not an outstanding G%d MSM of this curve", ticket, curve);
     typedef typename FastHost<Cv>::G HG;
     typename HG::X r;
     TRY(msm_collect<Cv>(ctx, L, &r));

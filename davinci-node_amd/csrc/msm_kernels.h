@@ -247,7 +247,10 @@ template <class Cv> __global__ void k_points_expand(u32* __restrict__ table, siz
     }
 }
 // signed c-bit digits (c <= 24) as int32: digits[(w - win_lo) * n + i] in [-2^(c-1), 2^(c-1) - 1]
-template <class S> __global__ void k_digits32(const u32* __restrict__ scalars, size_t n, u32 c, u32 win_lo, u32 win_hi, int* __restrict__ digits) {
+// flat_lo / flat_hi: only the entries whose flat position win * n + i lies in [flat_lo, flat_hi) are kept, the others become
+// zero digits (no entry): an MSM over an expanded table is shared between GPUs by entry count, not by whole rows
+template <class S> __global__ void k_digits32(const u32* __restrict__ scalars, size_t n, u32 c, u32 win_lo, u32 win_hi, int* __restrict__ digits,
+                                              u64 flat_lo, u64 flat_hi) {
     constexpr int EW = S::EW;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -274,7 +277,10 @@ template <class S> __global__ void k_digits32(const u32* __restrict__ scalars, s
         carry = 0;
         int v = (int)d;
         if (d >= nb) { v = (int)d - (int)(1u << c); carry = 1; }
-        if (win >= win_lo) digits[(size_t)(win - win_lo) * n + i] = v;
+        if (win >= win_lo) {
+            const u64 flat = (u64)win * n + i;
+            digits[(size_t)(win - win_lo) * n + i] = (flat >= flat_lo && flat < flat_hi) ? v : 0;
+        }
     }
 }
 // single block: bin_base = exclusive scan of bin_total (hb <= 2048), bin_base[hb] = totals[0] = number of entries

@@ -1,10 +1,13 @@
-"""Window-sharded MSM across the GPUs of one node (BASELINE.json north_star).
+"""One MSM / one proof shared between the GPUs of a node (BASELINE.json north_star).
 
-Every rank holds the whole device-resident point set and scalar vector, accumulates a contiguous slice of the
-Pippenger windows and reduces each to one point; the exchange is ONE all-gather of `ceil(nwin/world) x 128 B`
-per rank (RCCL over xGMI with backend "nccl", gloo in the CPU tests) -- RCCL has no elliptic-curve reduction
-operator, so the "all-reduce of partial bucket sums" is all-gather of bytes + the local Horner combine
-(dvn_msm_combine_g1).  At <= 2 KiB total the step is latency-bound, never link-bound.
+Every rank holds the whole device-resident point set and scalar vector and accumulates ITS SHARE of the Pippenger windows:
+for an expanded point set (row w = 2^(c w) P, all windows share one bucket set) the share is an equal range of the
+windows x n entries (`ShardedMsmPipeline`, dvn_msm_g1_share_*), which balances any world size -- 13 windows over 8 ranks are
+1.625 windows each -- and yields ONE partial sum per rank; the older per-window form (`sharded_msm_g1`, dvn_msm_g1_windows)
+returns a sum per window.  The exchange is ONE all-gather of 96 bytes (or `ceil(nwin/world) x 128 B`) per rank -- RCCL over
+xGMI with backend "nccl", gloo in the CPU tests.  RCCL has no elliptic-curve reduction operator, so the "all-reduce of
+partial bucket sums" is all-gather of bytes + a local sum (dvn_msm_g1_sum / dvn_msm_combine_g1).  Latency-bound, never
+link-bound.
 """
 from __future__ import annotations
 import numpy as np
@@ -46,23 +49,20 @@ def sharded_msm_g1(ctx, pts, scalars, n: int, rank: int, world: int, dist=None, 
 
 
 class ShardedMsmPipeline:
-    """Window-sharded G1 MSMs with two steps in flight per rank: the windows of step k+1 are queued on the GPU
-    (second lane) before the sums of step k are exchanged and combined, so the all-gather, the host combine and the
+    """G1 MSMs shared by entry count with several steps in flight per rank: the share of step k+1 is queued on the GPU
+    (another lane) before the partial sums of step k are exchanged and added, so the all-gather, the host sum and the
     latency-bound tail of one step hide under the accumulate kernel of the next."""
 
     def __init__(self, ctx, pts, n: int, rank: int, world: int, dist=None, device="cuda"):
         self.ctx, self.pts, self.n, self.rank, self.world, self.dist, self.device = ctx, pts, n, rank, world, dist, device
-        _, self.nwin, self.combine_bits = ctx.msm_plan_points(pts, n)
-        self.lo, self.hi = window_slice(self.nwin, world, rank)
         self.pending = []
 
-    def submit(self, scalars):
-        self.pending.append(self.ctx.msm_g1_windows_submit(self.pts, scalars, self.lo, self.hi, n=self.n))
+    def submit(self, d_scalars):
+        self.pending.append(self.ctx.msm_g1_share_submit(self.pts, d_scalars, self.n, self.rank, self.world))
 
     def collect(self):
-        sums = self.ctx.msm_g1_windows_collect(self.pending.pop(0))
-        allsums = exchange_window_sums(sums, self.nwin, self.world, self.rank, self.dist, self.device)
-        return self.ctx.msm_combine_g1(allsums, self.combine_bits)
+        part = self.ctx.msm_g1_share_collect(self.pending.pop(0))
+        return self.ctx.msm_g1_sum(all_gather_rows(part, self.world, self.dist, self.device))
 
     def in_flight(self) -> int:
         return len(self.pending)
@@ -81,7 +81,7 @@ def all_gather_rows(local: np.ndarray, world: int, dist=None, device="cpu") -> n
 
 
 def sharded_groth16_prove(key, witness, r_mont, s_mont, rank: int, world: int, dist=None, device="cuda") -> dict:
-    """One statetransition-style proof with its five MSMs sharded by rows across the ranks (BASELINE.json config 5): every
+    """One statetransition-style proof with its five MSMs shared by entry count across the ranks (BASELINE.json config 5): every
     rank computes its partial results (dvn_groth16_prove_shard), ONE all-gather of 576 bytes per rank, every rank assembles
     the same proof on the host (dvn_groth16_prove_combine)."""
     part = key.prove_shard(witness, rank, world)

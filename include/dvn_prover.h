@@ -13,8 +13,10 @@
  *   G2Affine {X.A0, X.A1, Y.A0, Y.A1}   16 x uint64
  *   G1Jac {X, Y, Z}           12 x uint64;  G2Jac 24 x uint64
  *
- * Return value: 0 = DVN_OK, negative = error; dvn_last_error(ctx) gives the message of the calling thread's
- * last failure.
+ * Return value: 0 = DVN_OK, negative = error; dvn_last_error(ctx) gives the message of the CALLING THREAD's last failure
+ * (thread-local).  A cgo caller must therefore pin its goroutine to the OS thread across the failing call and the
+ * dvn_last_error call (runtime.LockOSThread / UnlockOSThread, as the shim in integration/go does); dvn_error_string(code)
+ * is the thread-independent fallback text of a code.
  */
 #ifndef DVN_PROVER_H
 #define DVN_PROVER_H
@@ -39,10 +41,17 @@ typedef struct dvn_domain dvn_domain;   /* fft.Domain: twiddle tables for one si
 
 /* ---- lifetime ---------------------------------------------------------------------------------------- */
 /* Replaces icicle's device/runtime bring-up behind gpugroth16 (prover/prover_gpu.go:10-15).
- * devs/ndev: HIP device ordinals this context may use (NULL/0 = device 0).  One context per process-GPU. */
+ * devs/ndev: HIP device ordinals (NULL/0 = device 0).  EVERY listed ordinal gets a context: the handle returned serves
+ * devs[0], dvn_ctx_device(ctx, i) is the context of devs[i] (use it for uploads / key imports on that device), and the
+ * *_multi entry points spread one proof over all of them.  dvn_shutdown of the primary releases the others.  An ordinal may
+ * repeat (two contexts on one GPU), which is how a one-GPU machine rehearses the multi-device path. */
 int32_t dvn_init(const int* devs, int ndev, dvn_ctx** out);
 void dvn_shutdown(dvn_ctx* ctx);
+int32_t dvn_ctx_device_count(const dvn_ctx* ctx);
+dvn_ctx* dvn_ctx_device(dvn_ctx* ctx, int32_t index);
+int32_t dvn_ctx_device_ordinal(const dvn_ctx* ctx);
 const char* dvn_last_error(const dvn_ctx* ctx);
+const char* dvn_error_string(int32_t code);
 const char* dvn_version(void);
 
 /* ---- device memory helpers (bench/test harness; also used by the host orchestration) ------------------ */
@@ -63,8 +72,9 @@ int32_t dvn_points_upload_g2(dvn_ctx* ctx, const uint64_t* xy_mont, size_t n, dv
 int32_t dvn_points_synthetic_g1(dvn_ctx* ctx, uint64_t seed, size_t n, dvn_points** out);
 int32_t dvn_points_synthetic_g2(dvn_ctx* ctx, uint64_t seed, size_t n, dvn_points** out);
 /* (Re)build the set as an expanded table for window size window_bits in [11, 21] (row w = 2^(window_bits * w) * P_i,
- * 254 / window_bits + 1 rows), or collapse it back with 0.  G2 sets of >= 2^17 points are expanded
- * automatically at upload; G1 sets stay plain by default (measured: no gain). */
+ * 254 / window_bits + 1 rows), or collapse it back to a plain set with 0.  By default every set of >= 2^15 points, G1 or
+ * G2, is expanded at upload (window 16 below 2^18 points, 17 below 2^20, 20 from there) unless its table would exceed
+ * DVN_MSM_EXPAND_MAX_GB (16 GiB); DVN_MSM_EXPAND=0 turns the default off. */
 int32_t dvn_points_set_expanded(dvn_ctx* ctx, dvn_points* pts, uint32_t window_bits);
 /* Synthetic scalar vector written to DEVICE memory d_out (n x 4 uint64, gnark Montgomery form): kind 0 =
  * uniform mod r from SplitMix64 stream `seed`, kind 1 = the witness-like mixture of SURVEY.md §8d (40 % zero,
@@ -121,6 +131,17 @@ int32_t dvn_msm_g1_windows_collect(dvn_ctx* ctx, int32_t ticket, uint64_t* windo
 int32_t dvn_msm_combine_g1(dvn_ctx* ctx, const uint64_t* window_sums /* nwin x 16 */, uint32_t nwin, uint32_t window_bits,
                            uint64_t out_jac[12]);
 
+/* One MSM shared between the GPUs of a node BY ENTRY COUNT (north_star: "shard by Pippenger window ... all-reduce of partial
+ * bucket sums"): rank `rank` of `world` returns its share as a G1Jac image; the shares of all ranks add up to the MSM
+ * (dvn_msm_g1_sum, host only: RCCL has no elliptic-curve reduction, the ranks all-gather 96 bytes each).  On an expanded point
+ * set a share is an equal range of the windows x n entries -- balanced for any world size, where whole windows are not (13
+ * windows over 8 ranks); a set too small to be expanded is computed whole by rank 0.  Device scalars only.  Tickets are the
+ * lanes' (dvn_msm_g1_submit). */
+int32_t dvn_msm_g1_share_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* d_scalars_mont,
+                                uint32_t flags, uint32_t rank, uint32_t world, int32_t* ticket);
+int32_t dvn_msm_g1_share_collect(dvn_ctx* ctx, int32_t ticket, uint64_t partial_jac[12]);
+int32_t dvn_msm_g1_sum(const uint64_t* jacs /* count x 12 */, uint32_t count, uint64_t out_jac[12]);
+
 /* ---- fr/fft (replaces gnark-crypto fft.Domain) ------------------------------------- */
 #define DVN_DIF 0
 #define DVN_DIT 1
@@ -163,14 +184,29 @@ int32_t dvn_groth16_pk_free(dvn_ctx* ctx, dvn_groth16_pk* pk);
 int32_t dvn_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
                           const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32]);
 /* Sharded proving (BASELINE.json config 5: the statetransition proof's MSMs sharded across the GPUs of one node).  Every rank
- * holds the whole key and witness; rank `rank` of `world` runs the "solve" and computeH and ITS ROWS of the five MSMs
- * (dvn_groth16_prove_shard: 72 uint64 of partial results -- Jacobian images of A, B1, K, Z partial sums, 12 each, and of B2,
- * 24), the ranks all-gather the 576-byte buffers (RCCL), and dvn_groth16_prove_combine (host only) adds the partial results
- * and assembles the proof.  The key's point sets must be expanded (>= 2^15 points each; DVN_ERR_UNSUPPORTED otherwise). */
+ * holds the whole key and witness; rank `rank` of `world` runs the "solve" and computeH and ITS SHARE of the five MSMs -- an
+ * equal range of the (row, point) entries of every expanded key set, so 13 rows over 8 ranks are 1.625 rows each -- and
+ * returns 72 uint64 of partial results (Jacobian images of the A, B1, K, Z partial sums, 12 each, and of B2, 24); the ranks
+ * all-gather the 576-byte buffers (RCCL), and dvn_groth16_prove_combine (host only) adds them and assembles the proof.  A
+ * key set too small to be expanded (< 2^15 points) is computed whole by rank 0. */
 int32_t dvn_groth16_prove_shard(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
                                 uint32_t rank, uint32_t world, uint64_t partial_out[72]);
 int32_t dvn_groth16_prove_combine(const dvn_groth16_pk* pk, const uint64_t* partials /* world x 72 */, uint32_t world,
                                   const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32]);
+/* One proof over ALL devices of a multi-device context (dvn_init with ndev > 1): keys[i] is the same proving key resident
+ * on dvn_ctx_device(ctx, i) (built by dvn_groth16_setup or imported there).  Every device runs its share of the five MSMs --
+ * an equal range of the (row, point) entries of each expanded key set -- beside a replicated computeH, on a host thread of
+ * its own; the five partial sums per device return through pinned host memory and are added on the host.  One process holds
+ * every partial result, so no collective runs: the multi-PROCESS form (one rank per GPU, dvn_groth16_prove_shard + an RCCL
+ * all-gather of 576 bytes + dvn_groth16_prove_combine) stays available.  This shortens the node's serialisation point, one
+ * statetransition proof at a time (/root/reference/sequencer/statetransition.go:80).  Witness and (a, b, c) in HOST memory. */
+int32_t dvn_groth16_prove_multi(dvn_ctx* ctx, dvn_groth16_pk* const* keys, uint32_t nkeys, const uint64_t* witness,
+                                const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32]);
+/* per-proof statistics of the last prove call on this key as one JSON object (any curve): device ms until h is ready / after /
+ * total, device ms and pair count of each of the five MSMs, host-to-device bytes, algorithmic bytes and the achieved GB/s --
+ * the device-side detail behind the reference's "proof generated took=..." log line (/root/reference/circuits/artifacts.go:
+ * 572-577).  buf = NULL queries the size (needed, incl. the terminating 0). */
+int32_t dvn_groth16_last_stats_json(const dvn_groth16_pk* pk, char* buf, size_t cap, size_t* needed);
 /* device time of the last prove call (any curve): ms_h = start until h is ready on the main stream (witness copy, gathers,
  * "solve", computeH -- the B2, A, B1 and K MSMs already run beside it on the four lanes), ms_msm = from there to the last MSM, total */
 int32_t dvn_groth16_last_ms(const dvn_groth16_pk* pk, float* ms_h, float* ms_msm, float* ms_total);
@@ -193,14 +229,20 @@ int32_t dvn_groth16_proof_abi_encode(const uint64_t proof[32], const uint64_t co
  * defaultProver: if UseGPUProver (env GPU_PROVER in {true,y,1,yes}, prover/config.go:18-26) try the GPU and on ANY
  * error print "GPU proving failed (<err>), falling back to CPU" and run the CPU prover.  The CPU prover is the
  * embedder's (gnark groth16.Prove): register it with dvn_prover_set_cpu_backend; none registered -> error, never a
- * silent CPU computation.  curve ids: 1 BN254, 2 BLS12-377, 3 BLS12-381, 4 BW6-761 (only BN254 has a GPU path,
- * others return "GPU proving not supported for curve ..." like prover_gpu.go:58-60). */
+ * silent CPU computation.  curve ids: 1 BN254, 2 BLS12-377, 3 BLS12-381, 4 BW6-761 -- the four legs of callGPUProver
+ * (prover_gpu.go:27-57), each with a GPU path here; any other id returns "GPU proving not supported for curve ..." like
+ * prover_gpu.go:58-60.  witness / r / s / proof have the widths of the curve: scalars 4 uint64 (BW6-761: 6), proofs 32 uint64
+ * on BN254, 48 on the two BLS12 curves, 72 on BW6-761.  The package state (UseGPUProver, SetProver, the CPU backend) may be
+ * read and written from any thread. */
 typedef struct dvn_prover_request {
     int curve; dvn_ctx* ctx; const dvn_r1cs* ccs; dvn_groth16_pk* pk;
     const uint64_t* witness; const uint64_t* r; const uint64_t* s; uint64_t* proof;
 } dvn_prover_request;
 typedef int32_t (*dvn_prover_func)(const dvn_prover_request*, void* user);
-typedef int32_t (*dvn_cpu_backend)(int curve, const uint64_t* witness, const uint64_t* r, const uint64_t* s, uint64_t* proof, void* user);
+/* the CPU prover of the embedder (gnark's groth16.Prove): it receives what the reference's CPUProverWithWitness receives --
+ * the constraint system and the (plain) proving key next to the witness (prover_gpu.go:126-131) */
+typedef int32_t (*dvn_cpu_backend)(int curve, const dvn_r1cs* ccs, dvn_groth16_pk* pk, const uint64_t* witness, const uint64_t* r,
+                                   const uint64_t* s, uint64_t* proof, void* user);
 int32_t dvn_prover_use_gpu(void);
 void dvn_prover_set_use_gpu(int32_t on);
 void dvn_prover_reload_env(void);                                   /* re-run the package init(): read GPU_PROVER */
@@ -208,7 +250,7 @@ void dvn_prover_set_prover(dvn_prover_func p, void* user);          /* prover.Se
 void dvn_prover_set_cpu_backend(dvn_cpu_backend b, void* user);
 int32_t dvn_prover_last_backend(void);                              /* 1 GPU, 2 CPU backend, 3 custom prover func */
 int32_t dvn_prover_prove(dvn_ctx* ctx, int32_t curve, const dvn_r1cs* ccs, dvn_groth16_pk* pk, const uint64_t* witness,
-                         const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32]);
+                         const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out);
 int32_t dvn_prover_setup(dvn_ctx* ctx, const dvn_r1cs* ccs, uint64_t seed, dvn_groth16_pk** pk);   /* prover.Setup */
 
 /* ---- BLS12-377 ------------------------------------------------------------------------------------ */
@@ -329,6 +371,23 @@ int32_t dvn_groth16_prove_solved(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_
 /* arrays of a key built by dvn_groth16_setup in the import layout: which = 0..4 A, B, K, Z, B2; 5 / 6 idxA / idxB (uint32);
  * 7 the constants alpha1 | beta1 | delta1 | beta2 | delta2.  out = NULL queries the size in uint64 words. */
 int32_t dvn_groth16_pk_export_arrays(dvn_ctx* ctx, const dvn_groth16_pk* pk, int which, uint64_t* out, size_t cap_words, size_t* n_words);
+/* dvn_groth16_prove_solved over all devices of a multi-device context (see dvn_groth16_prove_multi): keys[i] imported on
+ * dvn_ctx_device(ctx, i) */
+int32_t dvn_groth16_prove_solved_multi(dvn_ctx* ctx, dvn_groth16_pk* const* keys, uint32_t nkeys, const uint64_t* w, const uint64_t* a,
+                                       const uint64_t* b, const uint64_t* c, size_t len, const uint64_t r_mont[4], const uint64_t s_mont[4],
+                                       uint64_t proof_out[32]);
+int32_t dvn_bw6761_groth16_prove_solved_multi(dvn_ctx* ctx, dvn_groth16_pk* const* keys, uint32_t nkeys, const uint64_t* w, const uint64_t* a,
+                                              const uint64_t* b, const uint64_t* c, size_t len, const uint64_t* r_mont, const uint64_t* s_mont,
+                                              uint64_t* proof_out);
+/* dvn_pedersen_commit on the other curves of callGPUProver's dispatch (/root/reference/prover/prover_gpu.go:36-57): the
+ * BSB22 commitment hint of the voteverifier (BLS12-377) and aggregator (BW6-761) circuits.  values: n scalars of the curve
+ * (4 / 4 / 6 uint64 each); outputs: G1Affine images (12 / 12 / 24 uint64).  The challenge hash-to-field stays in gnark. */
+int32_t dvn_bls12377_pedersen_commit(dvn_ctx* ctx, const dvn_points* basis, const dvn_points* basis_exp_sigma, const uint64_t* values_mont,
+                                     size_t n, uint32_t flags, uint64_t commitment_out[12], uint64_t pok_out[12]);
+int32_t dvn_bls12381_pedersen_commit(dvn_ctx* ctx, const dvn_points* basis, const dvn_points* basis_exp_sigma, const uint64_t* values_mont,
+                                     size_t n, uint32_t flags, uint64_t commitment_out[12], uint64_t pok_out[12]);
+int32_t dvn_bw6761_pedersen_commit(dvn_ctx* ctx, const dvn_points* basis, const dvn_points* basis_exp_sigma, const uint64_t* values_mont,
+                                   size_t n, uint32_t flags, uint64_t commitment_out[24], uint64_t pok_out[24]);
 
 /* the same three entry points on the other curves of prover_gpu.go's dispatch (element widths of that curve: G1 12 / 12 / 24,
  * G2 24 / 24 / 24 uint64 per affine point, scalars 4 / 4 / 6 uint64) */
@@ -344,6 +403,29 @@ int32_t dvn_bw6761_groth16_pk_import(dvn_ctx* ctx, const dvn_groth16_key_arrays*
 int32_t dvn_bw6761_groth16_prove_solved(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b,
                                         const uint64_t* c, size_t len, const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out);
 int32_t dvn_bw6761_groth16_pk_export_arrays(dvn_ctx* ctx, const dvn_groth16_pk* pk, int which, uint64_t* out, size_t cap_words, size_t* n_words);
+
+/* ---- gnark's artifact FILES ---------------------------------------------------------------------
+ * The node keeps proving keys as sha256-named files written by cmd/circuit-compile with pk.WriteTo
+ * (/root/reference/cmd/circuit-compile/main.go:507-513) and loads them with pk.UnsafeReadFrom
+ * (/root/reference/circuits/artifacts.go:391-406, hash check :123-133).  dvn_groth16_pk_load_file reads the same bytes
+ * (BN254; compressed or raw point encodings) straight into a device-resident key for dvn_groth16_prove_solved: the points
+ * are decompressed on the device, the InfinityA / InfinityB bitmaps become the wire lists of A and B, and K's wire list is
+ * [n_public, nbWires) minus committed_wires -- the two facts the key file does not carry come from the constraint system
+ * gnark loads beside it (ccs.GetNbPublicVariables(), the PrivateCommitted indices of its one commitment).  sha256_hex: the
+ * expected content hash (the file's name in the node's cache) or NULL; a mismatch is DVN_ERR_INVALID_ARG.  Keys are cached per
+ * context by content hash: loading the same file again returns the resident key, and cached keys live until dvn_shutdown
+ * (dvn_groth16_pk_free leaves them alone).  _load_bytes: the same reader on a memory image, uncached.  dvn_gnark_pk_scan
+ * (host only) reports the section sizes of an image: log_n, raw (0/1), nbWires, |A|, |B|, |Z|, |K|, |G2.B|, nbCommitmentKeys,
+ * |Basis[0]|, whether the domain header carries its flag byte.  The format lives in the un-vendored gnark module: it is
+ * restated from the published layout and exercised against this repository's own writer only. */
+int32_t dvn_gnark_pk_scan(const uint8_t* data, size_t len, uint64_t info[11]);
+int32_t dvn_groth16_pk_load_bytes(dvn_ctx* ctx, const uint8_t* data, size_t len, uint32_t n_public, const uint32_t* committed_wires,
+                                  uint32_t n_committed_wires, dvn_groth16_pk** out);
+int32_t dvn_groth16_pk_load_file(dvn_ctx* ctx, const char* path, const char* sha256_hex, uint32_t n_public,
+                                 const uint32_t* committed_wires, uint32_t n_committed_wires, dvn_groth16_pk** out);
+/* Basis / BasisExpSigma of a loaded key's commitment (NULL handles when it has none), owned by the key: the arguments of
+ * dvn_pedersen_commit in the solver's commitment hint */
+int32_t dvn_groth16_pk_commitment_bases(const dvn_groth16_pk* pk, const dvn_points** basis, const dvn_points** basis_exp_sigma);
 
 /* The verifying key of a Setup (the reference's Setup returns (pk, vk), /root/reference/prover/setup.go:15-28) as affine
  * Montgomery images of the key's curve: alpha (G1) | beta, gamma, delta (G2) | IC[n_public] (G1: CONSTANT and PUB_i of the

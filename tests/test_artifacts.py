@@ -1,0 +1,173 @@
+"""gnark proving-key artifact reader: the binary layout `pk.WriteTo` produces
+(/root/reference/cmd/circuit-compile/main.go:507-513) and `pk.UnsafeReadFrom` consumes
+(/root/reference/circuits/artifacts.go:391-406), read by csrc/dvn_artifacts.hip into a device-resident key.
+
+PARITY UNPINNED: the format lives in the un-vendored gnark module and no key file is reachable, so the reader is exercised
+against this repository's own writer (oracle/gnark_key_format_py.py), which restates the published layout.  What IS checked
+end to end: a key exported from the Setup mirror, written to a file in that layout (compressed and raw), loaded, and proved
+from reproduces the original key's proof bit for bit and the trapdoor closed form.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+
+
+def mont(o, x):
+    return np.array(o.limbs(o.to_mont(x % R, R)), dtype=np.uint64)
+
+
+def _tiny_image(opy, fmt, raw, domain_flag=True, commitment=False, n_wires=9):
+    o = opy
+    g = lambda k: o.g1_mul(o.G1_GEN, k)
+    h = lambda k: o.g2_mul(o.G2_GEN, k)
+    idxA, idxB = [0, 2, 3, 5], [1, 2, 8]
+    A = [g(3), g(4), None, g(6)]                     # a kept point may still be the point at infinity
+    B = [g(7), g(8), g(9)]
+    B2 = [h(7), h(8), h(9)]
+    Z = [g(20 + i) for i in range(4)]
+    K = [g(30 + i) for i in range(n_wires - 2 - (2 if commitment else 0))]
+    ck = [([g(50), g(51)], [g(60), g(61)])] if commitment else []
+    return fmt.write_proving_key(2, n_wires, A, B, Z, K, B2, idxA, idxB, (g(11), g(12), g(13), h(12), h(13)), ck, raw=raw, domain_flag=domain_flag)
+
+
+@pytest.mark.parametrize("raw", [False, True])
+@pytest.mark.parametrize("domain_flag", [True, False])
+def test_scan_reports_the_sections(pkg, opy, raw, domain_flag):
+    """Host only: section walk of a written image, compressed / raw, with and without the domain's flag byte."""
+    from oracle import gnark_key_format_py as fmt
+    img = _tiny_image(opy, fmt, raw, domain_flag, commitment=True)
+    info = pkg.gnark_pk_scan(img)
+    assert info == {"log_n": 2, "raw": int(raw), "n_wires": 9, "A": 4, "B": 3, "Z": 4, "K": 5, "B2": 3, "n_commitments": 1, "basis0": 2,
+                    "domain_flag": int(domain_flag)}
+    for bad in (img[:-1], img + b"\x00", img[:200], b"\x00" * 64, img[:8] + b"\xff" * (len(img) - 8)):
+        with pytest.raises(pkg.DvnError):
+            pkg.gnark_pk_scan(bad)
+    # a count that disagrees with the bitmaps is refused
+    broken = bytearray(img)
+    off = img.rindex(b"\x00\x00\x00\x00\x00\x00\x00\x09")         # nbWires (the last 8-byte big-endian 9 in the image)
+    broken[off + 15] ^= 1                                         # NbInfinityA
+    with pytest.raises(pkg.DvnError):
+        pkg.gnark_pk_scan(bytes(broken))
+
+
+def test_writer_point_encodings_round_trip(opy):
+    """The oracle's own encodings: flags, lexicographic rule, infinity, raw form."""
+    from oracle import gnark_key_format_py as fmt
+    o = opy
+    for k in (1, 2, 5, 12345, R - 1):
+        pt = o.g1_mul(o.G1_GEN, k)
+        for raw in (False, True):
+            b = fmt.g1_bytes(pt, raw)
+            assert len(b) == (64 if raw else 32) and fmt.g1_from_bytes(b) == (pt, len(b))
+        neg = (pt[0], o.P - pt[1])
+        assert (fmt.g1_bytes(pt, False)[0] ^ fmt.g1_bytes(neg, False)[0]) & 0xC0 == 0x40      # smallest 10 vs largest 11
+    assert fmt.g1_bytes(None, False)[0] == 0x40 and fmt.g1_from_bytes(fmt.g1_bytes(None, False)) == (None, 32)
+    assert fmt.g1_from_bytes(bytes(64)) == (None, 64)
+    q = o.g2_mul(o.G2_GEN, 77)
+    b = fmt.g2_bytes(q, False)
+    assert len(b) == 64 and b[0] & 0x80 and int.from_bytes(bytes([b[0] & 0x3F]) + b[1:32], "big") == q[0][1]   # X.A1 first
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("raw,domain_flag", [(False, True), (True, True), (False, False)])
+def test_key_file_round_trip_proves(ctx, pkg, opy, orc, tmp_path, raw, domain_flag):
+    """Setup -> export -> WRITE the gnark layout -> dvn_groth16_pk_load_file -> prove from the solver's output: the proof of the
+    original key, and the trapdoor closed form.  Also: content hash check, cache hit on the second load."""
+    from oracle import gnark_key_format_py as fmt
+    o = opy
+    n_c = 1500
+    cs = pkg.R1CS(7, n_c, 9)
+    key = pkg.Groth16Key(ctx, cs, 3)
+    arrays = key.export_arrays(cs.n_wires, cs.n_public)
+    A, B, Z, K, B2, consts = fmt.key_arrays_to_points(arrays)
+    img = fmt.write_proving_key(key.log_n, cs.n_wires, A, B, Z, K, B2, arrays["idxA"], arrays["idxB"], consts, raw=raw, domain_flag=domain_flag)
+    digest = hashlib.sha256(img).hexdigest()
+    path = tmp_path / digest                                   # the node names artifacts by their hash
+    path.write_bytes(img)
+    with pytest.raises(pkg.DvnError) as e:
+        pkg.LoadedKey(ctx, path, cs.n_public, sha256_hex="00" * 32)
+    assert "hash mismatch" in str(e.value)
+    lk = pkg.LoadedKey(ctx, path, cs.n_public, sha256_hex=digest)
+    assert lk.log_n == key.log_n
+    ref = o.SyntheticR1CS(n_c, 9, 7)
+    a, b, c = (np.array([o.limbs(o.to_mont(v, R)) for v in col], dtype=np.uint64) for col in ref.abc())
+    r, s = mont(o, 1234567), mont(o, 7654321)
+    got = lk.prove_solved(cs.witness(), a, b, c, r, s)
+    want = key.prove(cs.witness(), r, s)
+    _, closed = orc.groth16_synthetic_expected(7, n_c, 9, 3, r, s)
+    for k in ("Ar", "Bs", "Krs"):
+        assert (got[k] == want[k]).all() and (got[k] == closed[k]).all(), k
+    again = pkg.LoadedKey(ctx, path, cs.n_public, sha256_hex=digest.upper())
+    assert again.h.value == lk.h.value, "the second load of the same content returns the resident key"
+    lk.free()                                                  # cached keys outlive their handles ...
+    got2 = again.prove_solved(cs.witness(), a, b, c, r, s)     # ... and keep proving
+    assert (got2["Krs"] == closed["Krs"]).all()
+    # wrong n_public: the K count no longer matches
+    with pytest.raises(pkg.DvnError):
+        pkg.LoadedKey(ctx, img, cs.n_public + 1)
+    key.free(); cs.free()
+
+
+@pytest.mark.gpu
+def test_key_image_with_commitment_key(ctx, pkg, opy, orc):
+    """A key whose file carries one commitment key: K leaves the committed wires out (the proof's Krs lacks exactly their
+    terms), and the loaded Basis / BasisExpSigma feed dvn_pedersen_commit."""
+    from oracle import gnark_key_format_py as fmt
+    o = opy
+    n_c = 600
+    cs = pkg.R1CS(7, n_c, 9)
+    key = pkg.Groth16Key(ctx, cs, 3)
+    arrays = key.export_arrays(cs.n_wires, cs.n_public)
+    A, B, Z, K, B2, consts = fmt.key_arrays_to_points(arrays)
+    committed = [cs.n_public + 1, cs.n_public + 5, cs.n_public + 6, cs.n_wires - 1]
+    keepK = [i for i in range(cs.n_public, cs.n_wires) if i not in committed]
+    Kc = [K[i - cs.n_public] for i in keepK]
+    basis_l = orc.g1_synthetic_points(81, len(committed))
+    sigma = 0x1234567890ABCDEF
+    sig_l = np.array([orc.g1_mul(basis_l[i], sigma) for i in range(len(committed))], dtype=np.uint64)
+    ck = [([o.g1_from_limbs([int(v) for v in r]) for r in basis_l], [o.g1_from_limbs([int(v) for v in r]) for r in sig_l])]
+    img = fmt.write_proving_key(key.log_n, cs.n_wires, A, B, Z, Kc, B2, arrays["idxA"], arrays["idxB"], consts, ck)
+    assert pkg.gnark_pk_scan(img)["basis0"] == len(committed)
+    lk = pkg.LoadedKey(ctx, img, cs.n_public, committed_wires=committed)
+    w = cs.witness()
+    ref = o.SyntheticR1CS(n_c, 9, 7)
+    a, b, c = (np.array([o.limbs(o.to_mont(v, R)) for v in col], dtype=np.uint64) for col in ref.abc())
+    r, s = mont(o, 5), mont(o, 6)
+    got = lk.prove_solved(w, a, b, c, r, s)
+    _, closed = orc.groth16_synthetic_expected(7, n_c, 9, 3, r, s)
+    assert (got["Ar"] == closed["Ar"]).all() and (got["Bs"] == closed["Bs"]).all()
+    missing = orc.msm_g1(arrays["K"][[i - cs.n_public for i in committed]], w[committed])      # sum of the committed wires' K terms
+    assert (orc.g1_add(got["Krs"], missing) == closed["Krs"]).all()
+    bs, bsg = lk.commitment_bases()
+    cm, pok = ctx.pedersen_commit(bs, bsg, w[committed])
+    assert (cm == orc.msm_g1(basis_l, w[committed])).all() and (pok == orc.g1_mul(cm, sigma)).all()
+    st = lk.last_stats()
+    assert st["log_n"] == key.log_n and st["msm"]["G1.K"]["pairs"] == len(keepK) and st["bytes"]["host_to_device"] == w.nbytes + 3 * a.nbytes
+    lk.free(); key.free(); cs.free()
+
+
+@pytest.mark.gpu
+def test_malformed_points_are_rejected(ctx, pkg, opy):
+    from oracle import gnark_key_format_py as fmt
+    img = bytearray(_tiny_image(opy, fmt, raw=False))
+    off = 8 + 5 * 32 + 1 + 3 * 32 + 4                             # first point of G1.A
+    bad = bytearray(img); bad[off + 31] ^= 1                      # another x: on the curve only by chance; try a few
+    seen = False
+    for delta in range(1, 8):
+        bad = bytearray(img); bad[off + 31] = (img[off + 31] + delta) & 0xFF
+        try:
+            k = pkg.LoadedKey(ctx, bytes(bad), 2)
+            k.free()
+        except pkg.DvnError as e:
+            assert "not on the curve" in str(e)
+            seen = True
+            break
+    assert seen
+    mixed = bytearray(img); mixed[off] &= 0x3F                    # a raw-flagged point inside a compressed array
+    with pytest.raises(pkg.DvnError):
+        pkg.LoadedKey(ctx, bytes(mixed), 2)
+    ok = pkg.LoadedKey(ctx, bytes(img), 2)
+    ok.free()

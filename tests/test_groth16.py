@@ -127,11 +127,8 @@ def test_groth16_sharded_by_rows_recombines(ctx, pkg, opy, orc):
     from davinci_node_amd import sharding
     got = sharding.sharded_groth16_prove(key, dw, r, s, 0, 1)
     assert all((got[k] == ref[k]).all() for k in ("Ar", "Bs", "Krs"))
-    # a key with small (plain) sets cannot be row-sharded
-    cs2 = pkg.R1CS(7, 1000, 3); key2 = pkg.Groth16Key(ctx, cs2, 3)
-    with pytest.raises(pkg.DvnError):
-        key2.prove_shard(cs2.witness(), 0, 2)
-    key2.free(); cs2.free(); ctx.free(dw); key.free(); cs.free()
+    # (keys with small, plain sets: rank 0 computes those MSMs whole -- tests/test_multi_device.py)
+    ctx.free(dw); key.free(); cs.free()
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -47,7 +47,12 @@ def test_cpu_path_without_backend_errors_loudly(L, pkg):
 
 def _oracle_backend(orc, seeds, calls):
     from davinci_node_amd import binding
-    def cb(curve, wit, r, s, proof, user):
+    L_ = binding.load_library()
+    def cb(curve, ccs, pk, wit, r, s, proof, user):
+        # the reference's CPUProverWithWitness gets (ccs, pk, witness) (prover_gpu.go:126-131): so does the registered backend
+        assert ccs, "the CPU backend receives the constraint system"
+        info = [C.c_uint32(), C.c_uint32(), C.c_uint32()]
+        assert L_.dvn_r1cs_info(C.c_void_p(ccs), *[C.byref(x) for x in info]) == 0 and info[2].value == seeds[1]
         calls.append(curve)
         rr = np.ctypeslib.as_array(C.cast(r, C.POINTER(C.c_uint64)), (4,)).copy()
         ss = np.ctypeslib.as_array(C.cast(s, C.POINTER(C.c_uint64)), (4,)).copy()

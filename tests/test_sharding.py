@@ -34,7 +34,16 @@ def _worker(rank, world, port, n, c, q):
     # the fixed-size row all-gather of the sharded Groth16 prover (72 uint64 of partial results per rank)
     rows = sharding.all_gather_rows(np.arange(72, dtype=np.uint64) + 1000 * rank, world, dist, "cpu")
     rows_ok = rows.shape == (world, 72) and all((rows[r] == np.arange(72, dtype=np.uint64) + 1000 * r).all() for r in range(world))
-    q.put((rank, bool((got == want).all()) and rows_ok))
+    # the shared-by-entry-count form (dvn_msm_g1_share_* on a GPU): ONE partial sum per rank, all-gather of 96 bytes, host sum
+    # (dvn_msm_g1_sum).  Here a rank's share is the oracle's MSM over its half of the points.
+    lo_p, hi_p = rank * n // world, (rank + 1) * n // world
+    one = np.array([0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f7879462c, 0x0e0a77c19a07df2f], dtype=np.uint64)     # R mod p
+    part = np.concatenate([orc.msm_g1(pts[lo_p:hi_p], sc[lo_p:hi_p]), one])
+    gathered = sharding.all_gather_rows(part, world, dist, "cpu")
+    tot = np.zeros(12, dtype=np.uint64)
+    assert L.dvn_msm_g1_sum(C.c_void_p(gathered.ctypes.data), world, C.c_void_p(tot.ctypes.data)) == 0
+    share_ok = bool((orc.g1_jac_to_affine(tot) == want).all())
+    q.put((rank, bool((got == want).all()) and rows_ok and share_ok))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -91,3 +100,20 @@ def test_exchange_with_uneven_slices_world3():
         lo, hi = sharding.window_slice(nwin, world, r)
         out = sharding.exchange_window_sums(np.ascontiguousarray(full[lo:hi]), nwin, world, r, FakeDist(padded), "cpu")
         assert (out == full).all()
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """The real `bench.py --gpus 2` path (one process per rank, torch.distributed rendezvous, the MSM shared by entry count,
+    all-gather, host sum, result check) with both ranks on the one GPU of the box and gloo as the exchange backend."""
+    import json
+    import subprocess
+    env = dict(os.environ, DVN_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + os.getpid() % 300), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--log-n", "20", "--no-extras", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["result_checked"] is True and line["value"] > 0
+    assert line["roofline"]["pairs_per_launch"] == (1 << 20) // 2        # per-rank algorithmic bytes, not the whole MSM's
