@@ -106,8 +106,22 @@ template <class S> static int32_t ntt_domain_create(dvn_ctx* ctx, uint32_t log_n
     return DVN_OK;
 }
 
+constexpr size_t NTT_TILE_LDS_MAX = 73728;
+// dynamic LDS above the 64 KiB default needs the attribute once per kernel and device (with that device current)
+template <class S> static int32_t ntt_attrs(int device) {
+    static std::mutex mu;
+    static bool done[64] = {false};
+    std::lock_guard<std::mutex> lk(mu);
+    if (device < 0 || device >= 64) return fail(DVN_ERR_INVALID_ARG, "device ordinal %d out of range", device);
+    if (!done[device]) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_ntt_pass<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_TILE_LDS_MAX));
+        done[device] = true;
+    }
+    return DVN_OK;
+}
 // in-place transform of device data; asynchronous on ctx->stream
 template <class S> static int32_t ntt_device(dvn_ctx* ctx, const dvn_domain* d, u32* data, int inverse, int decimation, int coset) {
+    RoctxRange rr(inverse ? "dvn:ntt_inverse" : "dvn:ntt_forward");
     const u32 log_n = d->log_n;
     const u32 npass = (log_n + 7) / 8;
     const u32 base = log_n / npass, rem = log_n % npass;
@@ -127,9 +141,12 @@ template <class S> static int32_t ntt_device(dvn_ctx* ctx, const dvn_domain* d, 
         const u32 K = sb - sa;
         u32 log_i = 3;
         while (K + log_i > log_n) --log_i;                 // tile must not exceed the array
-        while (((size_t)1 << (K + log_i)) * S::EW * 4 > 65536) --log_i;      // tile <= 64 KiB of LDS (2048 8-word / 1024 12-word elements)
+        // an LDS slot is the element's NL limbs (ntt_kernels.h): tiles of 2048 nine-limb (72 KiB) / 1024 fourteen-limb (56 KiB)
+        // elements, two blocks per CU
+        while (((size_t)1 << (K + log_i)) * S::NL * 4 > NTT_TILE_LDS_MAX) --log_i;
         const u32 tiles = (u32)(((size_t)1 << log_n) >> (K + log_i));
-        const size_t lds = ((size_t)1 << (K + log_i)) * S::EW * 4;
+        const size_t lds = ((size_t)1 << (K + log_i)) * S::NL * 4;
+        TRY(ntt_attrs<S>(ctx->device));
         NttScale use = none;
         if (sc.mode && ((sc.when == 1 && p == 0) || (sc.when == 2 && p == npass - 1))) use = sc;
         k_ntt_pass<S><<<tiles, 512, lds, ctx->stream>>>(data, tw, log_n, sa, sb, decimation == DVN_DIT, log_i, use);

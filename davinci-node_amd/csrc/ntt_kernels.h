@@ -41,6 +41,32 @@ template <class S> __device__ __forceinline__ void st_fr_weak(const Fe<S>& v, u3
     for (int i = 0; i < S::EW; i += 4) *reinterpret_cast<uint4*>(p + i) = make_uint4(w[i], w[i + 1], w[i + 2], w[i + 3]);
 }
 
+// LDS slots hold an element as its NL 29-bit limbs, NOT as packed words: a round reads and writes the limbs the field
+// routines work on, so the per-round unpack (word -> limb bit slicing) and pack disappear from the inner loop.  Layout: limb
+// quads in planes of 16 bytes per element (plane k at k * E * 16), the NL % 4 remaining limbs in planes of 4 bytes per element
+// -- consecutive lanes touch consecutive 16-byte (4-byte) cells of a plane, so the accesses are free of bank conflicts
+// where 32-byte packed slots read as two 16-byte halves were not.  NL = 9: 36 bytes per element, a 2048-element tile is 72 KiB.
+template <class S> __device__ __forceinline__ Fe<S> lds_ld(const u32* lds, u32 e, u32 E) {
+    constexpr int NQ = S::NL / 4, NR = S::NL % 4;
+    Fe<S> v;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        const uint4 q = *reinterpret_cast<const uint4*>(lds + ((size_t)k * E + e) * 4);
+        v.v[4 * k] = q.x; v.v[4 * k + 1] = q.y; v.v[4 * k + 2] = q.z; v.v[4 * k + 3] = q.w;
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) v.v[4 * NQ + r] = lds[(size_t)NQ * E * 4 + (size_t)r * E + e];
+    return v;
+}
+template <class S> __device__ __forceinline__ void lds_st(u32* lds, u32 e, u32 E, const Fe<S>& v) {
+    constexpr int NQ = S::NL / 4, NR = S::NL % 4;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k)
+        *reinterpret_cast<uint4*>(lds + ((size_t)k * E + e) * 4) = make_uint4(v.v[4 * k], v.v[4 * k + 1], v.v[4 * k + 2], v.v[4 * k + 3]);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) lds[(size_t)NQ * E * 4 + (size_t)r * E + e] = v.v[4 * NQ + r];
+}
+
 // out[k] = base^(k) * first, k < count; thread handles `chunk` consecutive entries.  base/first internal form.
 template <class S> __global__ void k_powers(u32* __restrict__ out, const u32* __restrict__ base_first, size_t count, u32 chunk) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -89,7 +115,7 @@ template <class S> __device__ __forceinline__ Fe<S> ntt_red_small(const Fe<S>& x
 // Two stages per LDS round trip (radix-4 units held in registers); values in LDS are kept below 4p ("loose", limbs
 // normalised), so differences feed the twiddle multiplication after ONE carry pass and sums need one conditional
 // subtraction of 4p -- the multiplication itself tolerates operands up to 13p (bn254_field.h).
-template <class S> __global__ __launch_bounds__(512) void k_ntt_pass(u32* __restrict__ data, const u32* __restrict__ tw, u32 log_n,
+template <class S> __global__ __launch_bounds__(512, (S::NL <= 9 ? 4 : 2)) void k_ntt_pass(u32* __restrict__ data, const u32* __restrict__ tw, u32 log_n,
                                                   u32 sa, u32 sb, int dit, u32 log_i, NttScale sc) {
     typedef S C;
     typedef Fe<S> Fr;
@@ -105,7 +131,7 @@ template <class S> __global__ __launch_bounds__(512) void k_ntt_pass(u32* __rest
         const u32 gi = ((sp >> Lb) << (Lb + K)) | (D << Lb) | (sp & inner_mask);
         Fr v = ld_fr<S>(data + (size_t)gi * S::EW);
         if (sc.mode && sc.when == 1) v = fe_mul<C>(v, ntt_scale_factor<S>(sc, gi, log_n));
-        st_fr_weak<S>(v, lds + (size_t)le * S::EW);
+        lds_st<S>(lds, le, E, v);
     }
     __syncthreads();
     // ---- radix-4 rounds: executed stages t and t + 1
@@ -123,11 +149,9 @@ template <class S> __global__ __launch_bounds__(512) void k_ntt_pass(u32* __rest
             const u32 Db = ((dq >> dlo) << (dlo + 2)) | low;
             const u32 inner = (sp0 + q) & inner_mask;
             // x[hi][lo]: hi = bit dlo+1 of D, lo = bit dlo
-            u32* p00 = lds + (size_t)((Db << log_i) | q) * S::EW;
-            u32* p01 = lds + (size_t)(((Db | (1u << dlo)) << log_i) | q) * S::EW;
-            u32* p10 = lds + (size_t)(((Db | (2u << dlo)) << log_i) | q) * S::EW;
-            u32* p11 = lds + (size_t)(((Db | (3u << dlo)) << log_i) | q) * S::EW;
-            const Fr x00 = ld_fr<S>(p00), x01 = ld_fr<S>(p01), x10 = ld_fr<S>(p10), x11 = ld_fr<S>(p11);
+            const u32 p00 = (Db << log_i) | q, p01 = ((Db | (1u << dlo)) << log_i) | q;
+            const u32 p10 = ((Db | (2u << dlo)) << log_i) | q, p11 = ((Db | (3u << dlo)) << log_i) | q;
+            const Fr x00 = lds_ld<S>(lds, p00, E), x01 = lds_ld<S>(lds, p01, E), x10 = lds_ld<S>(lds, p10, E), x11 = lds_ld<S>(lds, p11, E);
             if (!dit) {
                 // stage s pairs over the HIGH bit (distance 2 << dlo), twiddle depends on the low bit;
                 // stage s+1 pairs over the LOW bit, one twiddle for the whole unit
@@ -136,10 +160,10 @@ template <class S> __global__ __launch_bounds__(512) void k_ntt_pass(u32* __rest
                 const Fr wb = ld_fr<S>(tab2 + (size_t)((low << Lb) | inner) * S::EW);
                 const Fr A0 = ntt_red<S>(fe_add_lazy<C>(x00, x10)), A1 = ntt_red<S>(fe_add_lazy<C>(x01, x11));
                 const Fr B0 = fe_mul<C>(fe_sub_lazy<C, 4>(x00, x10), wa0), B1 = fe_mul<C>(fe_sub_lazy<C, 4>(x01, x11), wa1);
-                st_fr_weak<S>(ntt_red<S>(fe_add_lazy<C>(A0, A1)), p00);
-                st_fr_weak<S>(fe_mul<C>(fe_sub_lazy<C, 4>(A0, A1), wb), p01);
-                st_fr_weak<S>(ntt_red_small<S>(fe_add_lazy<C>(B0, B1)), p10);
-                st_fr_weak<S>(fe_mul<C>(fe_sub_lazy<C, 2>(B0, B1), wb), p11);
+                lds_st<S>(lds, p00, E, ntt_red<S>(fe_add_lazy<C>(A0, A1)));
+                lds_st<S>(lds, p01, E, fe_mul<C>(fe_sub_lazy<C, 4>(A0, A1), wb));
+                lds_st<S>(lds, p10, E, ntt_red_small<S>(fe_add_lazy<C>(B0, B1)));
+                lds_st<S>(lds, p11, E, fe_mul<C>(fe_sub_lazy<C, 2>(B0, B1), wb));
             } else {
                 // stage s1 pairs over the LOW bit, one twiddle; stage s1-1 pairs over the HIGH bit, twiddle depends on the low bit
                 const Fr w1 = ld_fr<S>(tab1 + (size_t)((low << Lb) | inner) * S::EW);
@@ -149,10 +173,10 @@ template <class S> __global__ __launch_bounds__(512) void k_ntt_pass(u32* __rest
                 const Fr a00 = fe_add_lazy<C>(x00, t0), a01 = fe_sub_lazy<C, 2>(x00, t0);     // < 5.1p, < 6p
                 const Fr a10 = fe_add_lazy<C>(x10, t1), a11 = fe_sub_lazy<C, 2>(x10, t1);
                 const Fr u0 = fe_mul<C>(a10, w20), u1 = fe_mul<C>(a11, w21);
-                st_fr_weak<S>(ntt_red<S>(fe_add_lazy<C>(a00, u0)), p00);
-                st_fr_weak<S>(ntt_red<S>(fe_add_lazy<C>(a01, u1)), p01);
-                st_fr_weak<S>(ntt_red<S>(fe_sub_lazy<C, 2>(a00, u0)), p10);
-                st_fr_weak<S>(ntt_red<S>(fe_sub_lazy<C, 2>(a01, u1)), p11);
+                lds_st<S>(lds, p00, E, ntt_red<S>(fe_add_lazy<C>(a00, u0)));
+                lds_st<S>(lds, p01, E, ntt_red<S>(fe_add_lazy<C>(a01, u1)));
+                lds_st<S>(lds, p10, E, ntt_red<S>(fe_sub_lazy<C, 2>(a00, u0)));
+                lds_st<S>(lds, p11, E, ntt_red<S>(fe_sub_lazy<C, 2>(a01, u1)));
             }
         }
         __syncthreads();
@@ -169,16 +193,15 @@ template <class S> __global__ __launch_bounds__(512) void k_ntt_pass(u32* __rest
             const u32 D0 = ((dp >> dshift) << (dshift + 1)) | low, D1 = D0 | dist;
             const u32 j = (low << Lb) | ((sp0 + q) & inner_mask);
             const Fr w = ld_fr<S>(table + (size_t)j * S::EW);
-            u32* pa = lds + (size_t)((D0 << log_i) | q) * S::EW;
-            u32* pb = lds + (size_t)((D1 << log_i) | q) * S::EW;
-            const Fr a = ld_fr<S>(pa), b = ld_fr<S>(pb);
+            const u32 pa = (D0 << log_i) | q, pb = (D1 << log_i) | q;
+            const Fr a = lds_ld<S>(lds, pa, E), b = lds_ld<S>(lds, pb, E);
             if (!dit) {
-                st_fr_weak<S>(ntt_red<S>(fe_add_lazy<C>(a, b)), pa);
-                st_fr_weak<S>(fe_mul<C>(fe_sub_lazy<C, 4>(a, b), w), pb);
+                lds_st<S>(lds, pa, E, ntt_red<S>(fe_add_lazy<C>(a, b)));
+                lds_st<S>(lds, pb, E, fe_mul<C>(fe_sub_lazy<C, 4>(a, b), w));
             } else {
                 const Fr bt = fe_mul<C>(b, w);
-                st_fr_weak<S>(ntt_red<S>(fe_add_lazy<C>(a, bt)), pa);
-                st_fr_weak<S>(ntt_red<S>(fe_sub_lazy<C, 2>(a, bt)), pb);
+                lds_st<S>(lds, pa, E, ntt_red<S>(fe_add_lazy<C>(a, bt)));
+                lds_st<S>(lds, pb, E, ntt_red<S>(fe_sub_lazy<C, 2>(a, bt)));
             }
         }
         __syncthreads();
@@ -187,7 +210,7 @@ template <class S> __global__ __launch_bounds__(512) void k_ntt_pass(u32* __rest
     for (u32 le = threadIdx.x; le < E; le += blockDim.x) {
         const u32 q = le & (I - 1), D = le >> log_i, sp = sp0 + q;
         const u32 gi = ((sp >> Lb) << (Lb + K)) | (D << Lb) | (sp & inner_mask);
-        Fr v = ld_fr<S>(lds + (size_t)le * S::EW);
+        Fr v = lds_ld<S>(lds, le, E);
         if (sc.mode && sc.when == 2) st_fr<S>(fe_mul<C>(v, ntt_scale_factor<S>(sc, gi, log_n)), data + (size_t)gi * S::EW);
         else st_fr4<S>(v, data + (size_t)gi * S::EW);
     }
