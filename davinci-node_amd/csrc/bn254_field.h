@@ -208,6 +208,48 @@ template <class C> DVN_HD Fe<C> fe_add_nocarry(const Fe<C>& a, const Fe<C>& b) {
     for (int i = 0; i < C::NL; ++i) r.v[i] = a.v[i] + b.v[i];
     return r;
 }
+// ---- carry-free forms (NTT butterflies) ---------------------------------------------------------------------------
+// limb i of K p with limbs 0..NL-2 normalised; folds to a literal once the caller's limb loop is unrolled
+template <class C, int K> DVN_HD constexpr u32 fe_kp_limb(int i) {
+    u64 carry = 0;
+    u32 out = 0;
+    for (int j = 0; j <= i; ++j) {
+        const u64 v = (u64)C::p(j) * (u32)K + carry;
+        out = j < C::NL - 1 ? (u32)(v & LMASK) : (u32)v;
+        carry = v >> LB;
+    }
+    return out;
+}
+// a + K p - b with NO carry pass.  Each limb of K p below the top one is raised by 2^SH and the limb above it lowered by
+// 2^(SH-29) (the same amount), so no limb-wise difference goes negative while b's limbs are < 2^SH and b's top limb is
+// <= (K p)'s top limb - 2^(SH-29).  Result: value a + K p - b, limbs < (a's limb bound) + 2^SH + 2^29 -- not normalised, but a
+// valid FIRST operand of fe_mul against a normalised second operand as long as fe_mul_raw_fits<C>() accepts that bound.
+template <class C, int K, int SH> DVN_HD Fe<C> fe_sub_raw(const Fe<C>& a, const Fe<C>& b) {
+    static_assert(SH >= LB && SH <= 31, "offset pattern");
+    Fe<C> r;
+#pragma unroll
+    for (int i = 0; i < C::NL; ++i) {
+        const u32 k = fe_kp_limb<C, K>(i) + (i < C::NL - 1 ? (1u << SH) : 0u) - (i > 0 ? (1u << (SH - LB)) : 0u);
+        r.v[i] = a.v[i] + k - b.v[i];
+    }
+    return r;
+}
+// the 64-bit columns of fe_mul hold NL products of a raw limb (< max_limb) with a normalised one plus the reduction's NL
+// products of two normalised limbs plus a carry-in
+template <class C> DVN_HD constexpr bool fe_mul_raw_fits(u64 max_limb) {
+    const unsigned __int128 cols = (unsigned __int128)C::NL * max_limb * LMASK + (unsigned __int128)C::NL * LMASK * LMASK + ((unsigned __int128)1 << 36);
+    return (cols >> 64) == 0;
+}
+// one unsigned carry pass: limbs < 2^32 in, limbs 0..NL-2 normalised out
+template <class C> DVN_HD Fe<C> fe_normalise(const Fe<C>& a) {
+    Fe<C> r = a;
+#pragma unroll
+    for (int i = 0; i < C::NL - 1; ++i) {
+        r.v[i + 1] += r.v[i] >> LB;
+        r.v[i] &= LMASK;
+    }
+    return r;
+}
 // (a*b + c*d) / 2^261 mod p with ONE Montgomery reduction.  Limbs of all four < 2^29 (top limb free), values loose.
 template <class C> DVN_HD Fe<C> fe_mul_add(const Fe<C>& a, const Fe<C>& b, const Fe<C>& c, const Fe<C>& d) {
     constexpr int NL = C::NL;
@@ -260,6 +302,38 @@ template <class C> DVN_HD Fe<C> fe_canonical(const Fe<C>& a) {
     Fe<C> r;
 #pragma unroll
     for (int i = 0; i < C::NL; ++i) r.v[i] = neg ? a.v[i] : (u32)d[i];
+    return r;
+}
+
+// bits [OFF, OFF + 32) of a value with normalised limbs (get(i) = limb i); bits beyond 32 are dropped
+template <class C, int OFF, class G> DVN_HD constexpr u32 fe_window32(G get) {
+    constexpr int i0 = OFF / LB, o = OFF % LB;
+    u32 w = get(i0) >> o;
+    if (i0 + 1 < C::NL) w |= get(i0 + 1) << (LB - o);
+    if (i0 + 2 < C::NL && 2 * LB - o < 32) w |= get(i0 + 2) << (2 * LB - o);
+    return w;
+}
+// Any value below 2^(BITS + 6) with normalised limbs -> weak form (< 2p), exactly: subtract q p where q is the quotient
+// estimated from the 32-bit window of the value that starts 22 bits below p's top bit.  With t that window, P = p >> OFF
+// (2^21 <= P < 2^22) and M = floor(2^32 / (P + 1)):  t M / 2^32 <= t / (P + 1) <= x / p  and  x / p - t M / 2^32 < 2^-14 + 2^-4,
+// so q = floor(t M / 2^32) is floor(x / p) or one less and x - q p lies in [0, 2p).  x - q p is formed without borrows as
+// sum_i (x_i + q k_i) 2^(29 i) - q 2^(29 NL) with k_0 = 2^29 - p_0, k_i = 2^29 - p_i - 1: every term is non-negative, and the
+// final -q 2^(29 NL) is the part of the top limb that masking removes.
+template <class C> DVN_HD Fe<C> fe_reduce_full(const Fe<C>& x) {
+    constexpr int NL = C::NL, OFF = C::BITS - 22;
+    static_assert(C::BITS + 6 <= LB * NL, "headroom of the top limb");
+    constexpr u32 P = fe_window32<C, OFF>([](int i) constexpr { return C::p(i); });
+    static_assert(P >= (1u << 21) && P < (1u << 22), "window position");
+    constexpr u32 M = (u32)((1ull << 32) / (P + 1));
+    const u32 t = fe_window32<C, OFF>([&x](int i) { return x.v[i]; });
+    const u32 q = (u32)(((u64)t * M) >> 32);
+    u64 l[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) l[i] = (u64)q * (u32)((1u << LB) - C::p(i) - (i > 0 ? 1u : 0u)) + x.v[i];
+    Fe<C> r;
+#pragma unroll
+    for (int i = 0; i < NL - 1; ++i) { l[i + 1] += l[i] >> LB; r.v[i] = (u32)l[i] & LMASK; }
+    r.v[NL - 1] = (u32)l[NL - 1] & LMASK;
     return r;
 }
 

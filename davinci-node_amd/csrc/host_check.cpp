@@ -218,3 +218,30 @@ extern "C" void hc_hostfast_fp2_mul(int which, const uint64_t* a, const uint64_t
     if (which == 0) { typedef dvn_host::OpsFq2N<Fp377Cfg, 6, 5> O; O::F x, y; memcpy(&x, a, 96); memcpy(&y, b, 96); O::F z = inv ? O::inv(x) : O::mul(x, y); memcpy(r, &z, 96); }
     else { typedef dvn_host::OpsFq2N<Fp381Cfg, 6, 1> O; O::F x, y; memcpy(&x, a, 96); memcpy(&y, b, 96); O::F z = inv ? O::inv(x) : O::mul(x, y); memcpy(r, &z, 96); }
 }
+
+// ---- carry-free forms of the NTT butterflies, on raw limb arrays (NL uint32 each, no conversion) --------------------------
+// field: 0 BN254 Fr, 1 BLS12-377 Fr, 2 BLS12-381 Fr, 3 BLS12-377 Fp (BW6-761's scalar field).
+// op: 0 fe_reduce_full(a), 1 fe_sub_raw<8, 29>(a, b), 2 fe_sub_raw<16, 30>(a, b), 3 fe_sub_raw<2, 29>(a, b), 4 fe_normalise(a),
+//     5 fe_mul(a, b) with a raw (limbs up to 2.5 * 2^30) and b normalised, 6 fe_canonical(fe_reduce_full(a))
+template <class C> static void raw_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* r) {
+    Fe<C> x, y, z;
+    for (int i = 0; i < C::NL; ++i) { x.v[i] = a[i]; y.v[i] = b[i]; }
+    switch (op) {
+        case 0: z = fe_reduce_full<C>(x); break;
+        case 1: z = fe_sub_raw<C, 8, LB>(x, y); break;
+        case 2: z = fe_sub_raw<C, 16, 30>(x, y); break;
+        case 3: z = fe_sub_raw<C, 2, LB>(x, y); break;
+        case 4: z = fe_normalise<C>(x); break;
+        case 5: z = fe_mul<C>(x, y); break;
+        default: z = fe_canonical<C>(fe_reduce_full<C>(x)); break;
+    }
+    for (int i = 0; i < C::NL; ++i) r[i] = z.v[i];
+}
+extern "C" int hc_raw_op(int field, int op, const uint32_t* a, const uint32_t* b, uint32_t* r) {
+    switch (field) {
+        case 0: raw_op<FrCfg>(op, a, b, r); return FrCfg::NL;
+        case 1: raw_op<Fr377Cfg>(op, a, b, r); return Fr377Cfg::NL;
+        case 2: raw_op<Fr381Cfg>(op, a, b, r); return Fr381Cfg::NL;
+        default: raw_op<Fp377Cfg>(op, a, b, r); return Fp377Cfg::NL;
+    }
+}

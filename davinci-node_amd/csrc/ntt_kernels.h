@@ -94,27 +94,25 @@ template <class S> __device__ __forceinline__ Fe<S> ntt_scale_factor(const NttSc
     return f;
 }
 
-// values < 4p (the in-pass invariant) -> canonical -> 8 words
-template <class S> __device__ __forceinline__ void st_fr4(const Fe<S>& v, u32* __restrict__ p) { st_fr<S>(fe_csub<S, 2>(v), p); }
-
-// In-pass reduction of a value < 8p to what an 8-word LDS slot can hold: below 4p when 4p < 2^256 (BN254 and BLS12-377,
-// 254/253-bit moduli), below 2p for a 255-bit modulus (BLS12-381: 4p > 2^256), at the price of a second conditional
-// subtraction.
-template <class S> struct NttSlot { static constexpr bool WIDE = S::BITS + 2 <= 32 * S::EW; };
-template <class S> __device__ __forceinline__ Fe<S> ntt_red(const Fe<S>& x) {
-    if constexpr (NttSlot<S>::WIDE) return fe_csub<S, 4>(x);
-    else return fe_csub<S, 2>(fe_csub<S, 4>(x));
-}
-// a sum of two fresh products (< 2.5p): fits a wide slot as it is
-template <class S> __device__ __forceinline__ Fe<S> ntt_red_small(const Fe<S>& x) {
-    if constexpr (NttSlot<S>::WIDE) return x;
-    else return fe_csub<S, 2>(x);
-}
+// In-pass invariants: limbs in LDS are normalised (a slot is the NL limbs).  DIF rounds keep values below 4p (ntt_red brings
+// a value below 8p back under it): their sums would otherwise quadruple per round.  DIT rounds do not reduce at all: a
+// round's outputs are x +- t +- u (+ 2p per subtraction) with t, u fresh products below 2p, so a value grows by at most 4p
+// per round -- at most 2p + 4 * 4p = 18p over the 4 rounds of a pass, inside the 2^(BITS + 6) that fe_reduce_full takes at
+// the store and far inside what a multiplication by a canonical twiddle accepts.
+template <class S> __device__ __forceinline__ Fe<S> ntt_red(const Fe<S>& x) { return fe_csub<S, 4>(x); }
+// wide fields (NL > 9) leave less headroom in fe_mul's 64-bit columns: their raw operands are built from normalised sums
+template <class S> struct NttRaw {
+    static constexpr bool TIGHT = S::NL > 9;
+    static constexpr int SH_SUMS = TIGHT ? 29 : 30;       // limb bound of the sums S0, S1 below
+    static_assert(fe_mul_raw_fits<S>((1ull << SH_SUMS) + (1ull << SH_SUMS) + (1ull << LB)), "p01 operand");
+    static_assert(fe_mul_raw_fits<S>(3ull << LB), "operands built from two normalised values");
+};
 
 // stages [sa, sb) of a 2^log_n transform; dit = 0: ascending s (DIF), dit = 1: descending s (DIT).
-// Two stages per LDS round trip (radix-4 units held in registers); values in LDS are kept below 4p ("loose", limbs
-// normalised), so differences feed the twiddle multiplication after ONE carry pass and sums need one conditional
-// subtraction of 4p -- the multiplication itself tolerates operands up to 13p (bn254_field.h).
+// Two stages per LDS round trip (radix-4 units held in registers); values in LDS are kept below 4p with normalised limbs.
+// Differences feed the twiddle multiplication with NO carry pass (fe_sub_raw: the twiddle is canonical, so the product's
+// 64-bit columns have room for limbs up to 2.5 * 2^30 and the result is below 2p for operands up to 24p); only what is
+// stored without passing through a multiplication pays a carry pass and conditional subtractions.
 template <class S> __global__ __launch_bounds__(512, (S::NL <= 9 ? 4 : 2)) void k_ntt_pass(u32* __restrict__ data, const u32* __restrict__ tw, u32 log_n,
                                                   u32 sa, u32 sb, int dit, u32 log_i, NttScale sc) {
     typedef S C;
@@ -158,25 +156,27 @@ template <class S> __global__ __launch_bounds__(512, (S::NL <= 9 ? 4 : 2)) void 
                 const Fr wa0 = ld_fr<S>(tab1 + (size_t)((low << Lb) | inner) * S::EW);
                 const Fr wa1 = ld_fr<S>(tab1 + (size_t)((((1u << dlo) | low) << Lb) | inner) * S::EW);
                 const Fr wb = ld_fr<S>(tab2 + (size_t)((low << Lb) | inner) * S::EW);
-                const Fr A0 = ntt_red<S>(fe_add_lazy<C>(x00, x10)), A1 = ntt_red<S>(fe_add_lazy<C>(x01, x11));
-                const Fr B0 = fe_mul<C>(fe_sub_lazy<C, 4>(x00, x10), wa0), B1 = fe_mul<C>(fe_sub_lazy<C, 4>(x01, x11), wa1);
-                lds_st<S>(lds, p00, E, ntt_red<S>(fe_add_lazy<C>(A0, A1)));
-                lds_st<S>(lds, p01, E, fe_mul<C>(fe_sub_lazy<C, 4>(A0, A1), wb));
-                lds_st<S>(lds, p10, E, ntt_red_small<S>(fe_add_lazy<C>(B0, B1)));
-                lds_st<S>(lds, p11, E, fe_mul<C>(fe_sub_lazy<C, 2>(B0, B1), wb));
+                Fr S0 = fe_add_nocarry<C>(x00, x10), S1 = fe_add_nocarry<C>(x01, x11);                 // < 8p, limbs < 2^30
+                if constexpr (NttRaw<S>::TIGHT) { S0 = fe_normalise<C>(S0); S1 = fe_normalise<C>(S1); }
+                const Fr B0 = fe_mul<C>(fe_sub_raw<C, 8, LB>(x00, x10), wa0), B1 = fe_mul<C>(fe_sub_raw<C, 8, LB>(x01, x11), wa1);
+                lds_st<S>(lds, p00, E, fe_csub<C, 4>(fe_csub<C, 8>(fe_normalise<C>(fe_add_nocarry<C>(S0, S1)))));   // < 16p -> < 4p
+                lds_st<S>(lds, p01, E, fe_mul<C>(fe_sub_raw<C, 16, NttRaw<S>::SH_SUMS>(S0, S1), wb));   // operand < 24p
+                lds_st<S>(lds, p10, E, fe_add_lazy<C>(B0, B1));                                          // two products: < 4p
+                lds_st<S>(lds, p11, E, fe_mul<C>(fe_sub_raw<C, 2, LB>(B0, B1), wb));
             } else {
                 // stage s1 pairs over the LOW bit, one twiddle; stage s1-1 pairs over the HIGH bit, twiddle depends on the low bit
                 const Fr w1 = ld_fr<S>(tab1 + (size_t)((low << Lb) | inner) * S::EW);
                 const Fr w20 = ld_fr<S>(tab2 + (size_t)((low << Lb) | inner) * S::EW);
                 const Fr w21 = ld_fr<S>(tab2 + (size_t)((((1u << dlo) | low) << Lb) | inner) * S::EW);
-                const Fr t0 = fe_mul<C>(x01, w1), t1 = fe_mul<C>(x11, w1);
-                const Fr a00 = fe_add_lazy<C>(x00, t0), a01 = fe_sub_lazy<C, 2>(x00, t0);     // < 5.1p, < 6p
-                const Fr a10 = fe_add_lazy<C>(x10, t1), a11 = fe_sub_lazy<C, 2>(x10, t1);
+                const Fr t0 = fe_mul<C>(x01, w1), t1 = fe_mul<C>(x11, w1);                      // products: < 2p, normalised
+                const Fr a00 = fe_add_nocarry<C>(x00, t0), a01 = fe_sub_raw<C, 2, LB>(x00, t0);  // < 6p, limbs < 2^30 / 1.5 * 2^30
+                const Fr a10 = fe_add_nocarry<C>(x10, t1), a11 = fe_sub_raw<C, 2, LB>(x10, t1);
                 const Fr u0 = fe_mul<C>(a10, w20), u1 = fe_mul<C>(a11, w21);
-                lds_st<S>(lds, p00, E, ntt_red<S>(fe_add_lazy<C>(a00, u0)));
-                lds_st<S>(lds, p01, E, ntt_red<S>(fe_add_lazy<C>(a01, u1)));
-                lds_st<S>(lds, p10, E, ntt_red<S>(fe_sub_lazy<C, 2>(a00, u0)));
-                lds_st<S>(lds, p11, E, ntt_red<S>(fe_sub_lazy<C, 2>(a01, u1)));
+                // no reduction: a DIT round adds at most 4p to a value (see the bound above the kernel)
+                lds_st<S>(lds, p00, E, fe_normalise<C>(fe_add_nocarry<C>(a00, u0)));
+                lds_st<S>(lds, p01, E, fe_normalise<C>(fe_add_nocarry<C>(a01, u1)));
+                lds_st<S>(lds, p10, E, fe_normalise<C>(fe_sub_raw<C, 2, LB>(a00, u0)));
+                lds_st<S>(lds, p11, E, fe_normalise<C>(fe_sub_raw<C, 2, LB>(a01, u1)));
             }
         }
         __syncthreads();
@@ -197,11 +197,11 @@ template <class S> __global__ __launch_bounds__(512, (S::NL <= 9 ? 4 : 2)) void 
             const Fr a = lds_ld<S>(lds, pa, E), b = lds_ld<S>(lds, pb, E);
             if (!dit) {
                 lds_st<S>(lds, pa, E, ntt_red<S>(fe_add_lazy<C>(a, b)));
-                lds_st<S>(lds, pb, E, fe_mul<C>(fe_sub_lazy<C, 4>(a, b), w));
+                lds_st<S>(lds, pb, E, fe_mul<C>(fe_sub_raw<C, 8, LB>(a, b), w));
             } else {
                 const Fr bt = fe_mul<C>(b, w);
-                lds_st<S>(lds, pa, E, ntt_red<S>(fe_add_lazy<C>(a, bt)));
-                lds_st<S>(lds, pb, E, ntt_red<S>(fe_sub_lazy<C, 2>(a, bt)));
+                lds_st<S>(lds, pa, E, fe_normalise<C>(fe_add_nocarry<C>(a, bt)));
+                lds_st<S>(lds, pb, E, fe_normalise<C>(fe_sub_raw<C, 2, LB>(a, bt)));
             }
         }
         __syncthreads();
@@ -212,7 +212,7 @@ template <class S> __global__ __launch_bounds__(512, (S::NL <= 9 ? 4 : 2)) void 
         const u32 gi = ((sp >> Lb) << (Lb + K)) | (D << Lb) | (sp & inner_mask);
         Fr v = lds_ld<S>(lds, le, E);
         if (sc.mode && sc.when == 2) st_fr<S>(fe_mul<C>(v, ntt_scale_factor<S>(sc, gi, log_n)), data + (size_t)gi * S::EW);
-        else st_fr4<S>(v, data + (size_t)gi * S::EW);
+        else st_fr<S>(fe_reduce_full<S>(v), data + (size_t)gi * S::EW);
     }
 }
 

@@ -116,3 +116,68 @@ def test_hostfast_wide_fields(hc, which, name):
             hc.hc_hostfast_fp2_mul(which, q(A), q(B), q(r2), 1)
             d = pow((a0 * a0 + beta * a1 * a1) % p_, -1, p_)
             assert (dec(r2[:6]), dec(r2[6:])) == (a0 * d % p_ * Rm % p_, (-a1 * d) % p_ * Rm % p_)
+
+
+@pytest.mark.parametrize("field", [0, 1, 2, 3])
+def test_carry_free_butterfly_forms(hc, field):
+    """The forms the NTT butterflies use instead of carry passes and conditional subtractions, on raw limb arrays:
+    fe_sub_raw (a + K p - b with no negative limb), fe_normalise, a multiplication whose first operand is such a raw value,
+    and fe_reduce_full (any value below 2^(BITS + 6) -> below 2p, exactly), on every scalar field the NTT is built for.
+    Adversarial values: multiples of p and their neighbours, all-ones limbs, the largest value each form is specified for."""
+    import random
+    from oracle import curves_py as cp
+    from oracle import bn254_py as o
+    mod = {0: o.R, 1: cp.BLS12_377.r, 2: cp.BLS12_381.r, 3: cp.BLS12_377.p}[field]
+    nl = 14 if field == 3 else 9
+    bits = mod.bit_length()
+    B = 1 << 29
+    norm = lambda x: [(x >> (29 * i)) & (B - 1) for i in range(nl - 1)] + [x >> (29 * (nl - 1))]
+    val = lambda l: sum(int(v) << (29 * i) for i, v in enumerate(l))
+    arr = lambda l: np.array(l, dtype=np.uint32)
+    out = np.zeros(nl, dtype=np.uint32)
+    zero = arr([0] * nl)
+
+    def call(op, a, b=None):
+        assert hc.hc_raw_op(field, op, p(arr(a)), p(arr(b) if b is not None else zero), p(out)) == nl
+        return [int(v) for v in out]
+
+    rng = random.Random(field)
+    # fe_reduce_full: x < 2^(bits + 6)
+    top = 1 << (bits + 6)
+    xs = [0, 1, mod - 1, mod, mod + 1, 2 * mod - 1, 2 * mod, top - 1, top - mod, (top // mod) * mod, (top // mod) * mod - 1]
+    xs += [k * mod + d for k in (1, 2, 3, 7, 18, 19, 31, 63) for d in (-1, 0, 1) if 0 <= k * mod + d < top]
+    xs += [rng.randrange(top) for _ in range(3000)] + [rng.randrange(20) * mod + rng.randrange(1 << 40) for _ in range(500)]
+    for x in xs:
+        got = call(0, norm(x))
+        assert all(v < B for v in got) and val(got) < 2 * mod and val(got) % mod == x % mod and (x - val(got)) % mod == 0, hex(x)
+        assert x - val(got) in ((x // mod) * mod, (x // mod - 1) * mod)
+        assert val(call(6, norm(x))) == x % mod
+    # fe_sub_raw<K, SH>: b's limbs < 2^SH, b's value at most K p / 2 (the callers' bound), a anything with limbs < 2^30
+    for op, K, SH in ((1, 8, 29), (2, 16, 30), (3, 2, 29)):
+        bmax = K * mod // 2
+        for it in range(1500):
+            a = [rng.randrange(1 << 30) for _ in range(nl - 1)] + [rng.randrange(1 << 20)]
+            if it % 3 == 0:
+                bl = norm(rng.randrange(bmax))
+            elif it % 3 == 1:
+                bl = norm(bmax - 1 - rng.randrange(1 << 30))
+            else:                                              # un-normalised subtrahend: a sum of two normalised values
+                b1, b2 = rng.randrange(bmax // 2), rng.randrange(bmax // 2)
+                bl = [u + v for u, v in zip(norm(b1), norm(b2))] if SH == 30 else norm(b1 + b2)
+            if it == 5 and norm(bmax)[-1] >= 1:
+                bl = [(1 << SH) - 1] * (nl - 1) + [norm(bmax)[-1] - 1]     # every limb at its bound
+            got = call(op, a, bl)
+            assert val(got) == val(a) + K * mod - val(bl), (op, it)          # exact as integers: no limb wrapped
+            assert all(v < (1 << 30) + (1 << SH) + B for v in got)
+            n = call(4, got)
+            assert val(n) == val(got) and all(v < B for v in n[:-1])
+    # a raw first operand (limbs up to 2.5 * 2^30 on 9-limb fields, 1.5 * 2^30 on wider ones) times a canonical one
+    lim = (5 << 29) if nl == 9 else (3 << 29)
+    Rinv = pow(1 << (29 * nl), -1, mod)
+    for it in range(1500):
+        a = [lim - 1 - (rng.randrange(4) if it % 2 else rng.randrange(lim)) for _ in range(nl - 1)] + [rng.randrange(1 << 26)]
+        if val(a) >= 24 * mod:
+            a[-1] = rng.randrange(max(1, (20 * mod) >> (29 * (nl - 1))))
+        w = norm(mod - 1 - rng.randrange(1 << 50) if it % 2 else rng.randrange(mod))
+        got = call(5, a, w)
+        assert all(v < B for v in got[:-1]) and val(got) < 2 * mod and val(got) % mod == val(a) * val(w) * Rinv % mod, it
