@@ -149,7 +149,7 @@ template <class S> static int32_t ntt_device(dvn_ctx* ctx, const dvn_domain* d, 
         TRY(ntt_attrs<S>(ctx->device));
         NttScale use = none;
         if (sc.mode && ((sc.when == 1 && p == 0) || (sc.when == 2 && p == npass - 1))) use = sc;
-        k_ntt_pass<S><<<tiles, 512, lds, ctx->stream>>>(data, tw, log_n, sa, sb, decimation == DVN_DIT, log_i, use);
+        k_ntt_pass<S><<<tiles, 512, lds, ctx->stream>>>(data, tw, log_n, sa, sb, decimation == DVN_DIT, p == npass - 1, log_i, use);
         HIP_TRY(hipGetLastError());
     }
     return DVN_OK;

@@ -33,7 +33,7 @@ template <class S> __device__ __forceinline__ void st_fr(const Fe<S>& v, u32* __
 #pragma unroll
     for (int i = 0; i < S::EW; i += 4) *reinterpret_cast<uint4*>(p + i) = make_uint4(w[i], w[i + 1], w[i + 2], w[i + 3]);
 }
-// LDS staging keeps weak form (no canonicalisation between stages)
+// packs the value as it is (no canonicalisation): limbs normalised, value below 2^(32 EW)
 template <class S> __device__ __forceinline__ void st_fr_weak(const Fe<S>& v, u32* p) {
     u32 w[S::EW];
     fe_pack<S>(v, w);
@@ -100,6 +100,7 @@ template <class S> __device__ __forceinline__ Fe<S> ntt_scale_factor(const NttSc
 // per round -- at most 2p + 4 * 4p = 18p over the 4 rounds of a pass, inside the 2^(BITS + 6) that fe_reduce_full takes at
 // the store and far inside what a multiplication by a canonical twiddle accepts.
 template <class S> __device__ __forceinline__ Fe<S> ntt_red(const Fe<S>& x) { return fe_csub<S, 4>(x); }
+template <class S> struct NttBetween { static constexpr bool RAW_4P = S::BITS + 2 <= 32 * S::EW; };
 // wide fields (NL > 9) leave less headroom in fe_mul's 64-bit columns: their raw operands are built from normalised sums
 template <class S> struct NttRaw {
     static constexpr bool TIGHT = S::NL > 9;
@@ -108,13 +109,14 @@ template <class S> struct NttRaw {
     static_assert(fe_mul_raw_fits<S>(3ull << LB), "operands built from two normalised values");
 };
 
-// stages [sa, sb) of a 2^log_n transform; dit = 0: ascending s (DIF), dit = 1: descending s (DIT).
+// stages [sa, sb) of a 2^log_n transform; dit = 0: ascending s (DIF), dit = 1: descending s (DIT); last = 1 on the pass
+// that finishes the transform (its store is canonical).
 // Two stages per LDS round trip (radix-4 units held in registers); values in LDS are kept below 4p with normalised limbs.
 // Differences feed the twiddle multiplication with NO carry pass (fe_sub_raw: the twiddle is canonical, so the product's
 // 64-bit columns have room for limbs up to 2.5 * 2^30 and the result is below 2p for operands up to 24p); only what is
 // stored without passing through a multiplication pays a carry pass and conditional subtractions.
 template <class S> __global__ __launch_bounds__(512, (S::NL <= 9 ? 4 : 2)) void k_ntt_pass(u32* __restrict__ data, const u32* __restrict__ tw, u32 log_n,
-                                                  u32 sa, u32 sb, int dit, u32 log_i, NttScale sc) {
+                                                  u32 sa, u32 sb, int dit, int last, u32 log_i, NttScale sc) {
     typedef S C;
     typedef Fe<S> Fr;
     extern __shared__ __align__(16) u32 lds[];
@@ -156,11 +158,13 @@ template <class S> __global__ __launch_bounds__(512, (S::NL <= 9 ? 4 : 2)) void 
                 const Fr wa0 = ld_fr<S>(tab1 + (size_t)((low << Lb) | inner) * S::EW);
                 const Fr wa1 = ld_fr<S>(tab1 + (size_t)((((1u << dlo) | low) << Lb) | inner) * S::EW);
                 const Fr wb = ld_fr<S>(tab2 + (size_t)((low << Lb) | inner) * S::EW);
+                // differences first: the four inputs are dead after these four lines (register pressure, not arithmetic, orders this)
+                const Fr D0 = fe_sub_raw<C, 8, LB>(x00, x10), D1 = fe_sub_raw<C, 8, LB>(x01, x11);
                 Fr S0 = fe_add_nocarry<C>(x00, x10), S1 = fe_add_nocarry<C>(x01, x11);                 // < 8p, limbs < 2^30
                 if constexpr (NttRaw<S>::TIGHT) { S0 = fe_normalise<C>(S0); S1 = fe_normalise<C>(S1); }
-                const Fr B0 = fe_mul<C>(fe_sub_raw<C, 8, LB>(x00, x10), wa0), B1 = fe_mul<C>(fe_sub_raw<C, 8, LB>(x01, x11), wa1);
                 lds_st<S>(lds, p00, E, fe_csub<C, 4>(fe_csub<C, 8>(fe_normalise<C>(fe_add_nocarry<C>(S0, S1)))));   // < 16p -> < 4p
                 lds_st<S>(lds, p01, E, fe_mul<C>(fe_sub_raw<C, 16, NttRaw<S>::SH_SUMS>(S0, S1), wb));   // operand < 24p
+                const Fr B0 = fe_mul<C>(D0, wa0), B1 = fe_mul<C>(D1, wa1);
                 lds_st<S>(lds, p10, E, fe_add_lazy<C>(B0, B1));                                          // two products: < 4p
                 lds_st<S>(lds, p11, E, fe_mul<C>(fe_sub_raw<C, 2, LB>(B0, B1), wb));
             } else {
@@ -212,7 +216,13 @@ template <class S> __global__ __launch_bounds__(512, (S::NL <= 9 ? 4 : 2)) void 
         const u32 gi = ((sp >> Lb) << (Lb + K)) | (D << Lb) | (sp & inner_mask);
         Fr v = lds_ld<S>(lds, le, E);
         if (sc.mode && sc.when == 2) st_fr<S>(fe_mul<C>(v, ntt_scale_factor<S>(sc, gi, log_n)), data + (size_t)gi * S::EW);
-        else st_fr<S>(fe_reduce_full<S>(v), data + (size_t)gi * S::EW);
+        else if (last) st_fr<S>(fe_reduce_full<S>(v), data + (size_t)gi * S::EW);
+        else {
+            // between the passes of one transform the array need not be canonical: the next pass takes what its first round
+            // takes from LDS (DIF: below 4p, when that fits the EW words; otherwise below 2p, DIT's starting bound)
+            if (!(NttBetween<S>::RAW_4P && !dit)) v = fe_reduce_full<S>(v);
+            st_fr_weak<S>(v, data + (size_t)gi * S::EW);
+        }
     }
 }
 

@@ -1,0 +1,11 @@
+"""Print the headline fields of a bench.py JSON line (file argument), one per row."""
+import json, sys
+d = json.load(open(sys.argv[1]))
+print("value", d["value"], d["unit"], "ms_per_step", d["ms_per_step"])
+r = d["roofline"]
+print("kernel_ms", r["kernel_ms"], "frac", r["frac"], "int frac", r.get("int_issue_context", {}).get("frac"))
+print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["unit"], d["cpu_baseline"]["cores"])
+for k, v in d["config"].items():
+    print("config", k, v)
+for k, v in d.get("extras", {}).items():
+    print("extra", k, json.dumps(v)[:260])
