@@ -2,17 +2,17 @@
 """bench.py -- BN254 G1 MSM throughput on MI355X through the C-ABI (include/dvn_prover.h).
 
 Metric (BASELINE.json): "BN254 G1 MSM Mscalar/s @2^22".  One step = one 2^22-point MultiExp (gnark-crypto
-G1Jac.MultiExp semantics, SURVEY.md §8 row a12) with points AND scalars already resident in HBM.
+G1Jac.MultiExp semantics) with points AND scalars already resident in HBM.
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-N > 1: the MSM is sharded by Pippenger window (SURVEY.md §8e): every rank holds the whole point set and scalar
+N > 1: the MSM is sharded by Pippenger window: every rank holds the whole point set and scalar
 vector, accumulates its slice of the windows, the per-window sums (<= 2 KiB) are exchanged with one RCCL
 all-gather, and every rank finishes with the host Horner combine.  Total work is fixed -> "scaling": "strong".
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (k_accumulate): algorithmic bytes =
-96 B per (scalar, point) pair (SURVEY.md §8d) x pairs per launch, divided by that kernel's mean launch duration
+96 B per (scalar, point) pair x pairs per launch, divided by that kernel's mean launch duration
 measured with HIP events on the library's stream.  `cpu_baseline` is the C oracle (own Pippenger, NOT gnark)
 timed on this host's cores over a bounded sample.
 """
@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-BYTES_PER_PAIR = 96            # 32 B scalar + 64 B affine point, SURVEY.md §8d
+BYTES_PER_PAIR = 96            # 32 B scalar + 64 B affine point
 # secondary (integer-issue) roofline of the dominant kernel -- context only, the contract's roofline is the HBM one:
 MADS_PER_ADD = 1467            # v_mad_u64_u32 per XYZZ mixed addition in k_accumulate's loop body (counted in the ISA)
 MAD_PEAK_PER_S = 35.4e12       # chip-wide v_mad_u64_u32 lane-op/s measured by tools/microbench (profiles/r01_instr_rate_microbench.txt)
@@ -308,7 +308,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_extras:
         extras = {}
-        # config 2 (2^20) and the witness-like scalar mixture of SURVEY.md §8d (40 % zero, 25 % one, 25 % < 2^64, 10 % uniform),
+        # config 2 (2^20) and the witness-like scalar mixture (40 % zero, 25 % one, 25 % < 2^64, 10 % uniform),
         # same point set, three MSMs in flight as in the timed region; every result against the closed form
         def msm_rate(nn, dscal, reps=12):
             tk = []
@@ -351,7 +351,7 @@ def main():
                                            "achieved_GBps": round(2 * (1 << ln) * 64 / (fi * 1e-3) / 1e9, 1),
                                            "frac_of_hbm_peak": round(2 * (1 << ln) * 64 / (fi * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                                            "round_trip_identity": bool((x0 == x1).all())}
-        # config 4 ("aggregator full PLONK proof"): the reference has no PLONK circuit (SURVEY.md §8d) -- this is an explicitly
+        # config 4 ("aggregator full PLONK proof"): the reference has no PLONK circuit -- this is an explicitly
         # SYNTHETIC COMPOSITION of the two primitives in the shape of a PLONK prover with 2^22 gates over one KZG SRS:
         # 9 commitment / opening MSMs of 2^22 (L, R, O, Z, H1..H3, W_z, W_zw) with three in flight, 4 iNTT of 2^22,
         # 8 coset NTTs and 1 coset iNTT over the 4n = 2^24 quotient domain.  The reference-faithful aggregator proof is
@@ -445,7 +445,7 @@ def main():
                 ik.free(); del wh, ah, bh, ch
             ctx.free(dw); key.free(); cs.free()
 
-        # the same shape at n = 2^22 constraints (SURVEY.md §8d config 5's nominal size), BN254
+        # the same shape at n = 2^22 constraints (the proof metric's nominal size), BN254
         cs = pkg.R1CS(7, 1 << 22, 9)
         key = pkg.Groth16Key(ctx, cs, 3)
         dw = ctx.to_device(cs.witness())
@@ -504,7 +504,7 @@ def main():
                 list(first["Commitment"]) == opy.g1_to_limbs(wantc["Commitment"]) and list(first["CommitmentPok"]) == opy.g1_to_limbs(wantc["CommitmentPok"])
                 and list(first["Ar"]) == opy.g1_to_limbs(wantc["Ar"]) and list(first["Bs"]) == opy.g2_to_limbs(wantc["Bs"]) and list(first["Krs"]) == opy.g1_to_limbs(wantc["Krs"]))
         ctx.free(dw); key.free(); cs.free()
-        # row f3: what BlobEvalData.Set costs before every state-transition proof (crypto/blobs/blob.go:40-90): blob commitment,
+        # what BlobEvalData.Set costs before every state-transition proof (crypto/blobs/blob.go:40-90): blob commitment,
         # 128 cell proofs and the opening proof at z, over the trusted setup the reference embeds (tests/golden copy)
         golden = os.path.join(ROOT, "tests", "golden")
         if os.path.exists(os.path.join(golden, "kzg_trusted_setup.txt")):
@@ -554,7 +554,7 @@ def main():
                          "kernel_ms_note": f"mean HIP-event duration of the launch while {DEPTH} MSMs share the GPU; config.kernel_ms_solo is the same kernel alone",
                          "pairs_per_launch": pairs_per_launch,
                          "device_ms_per_step": round(float(np.mean(dev_ms)), 4),
-                         "int_issue_context": {"note": "kernel is v_mad_u64_u32-issue bound, not HBM bound (DESIGN.md \u00a74)",
+                         "int_issue_context": {"note": "kernel is v_mad_u64_u32-issue bound, not HBM bound",
                                                "mixed_additions_per_launch": adds_per_launch,
                                                "mad_per_addition": MADS_PER_ADD,
                                                "achieved_Tmad_per_s": round(adds_per_launch * MADS_PER_ADD / (acc * 1e-3) / 1e12, 2),

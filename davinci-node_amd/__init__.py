@@ -1,7 +1,7 @@
 """davinci-node_amd: MI355X-native prover backend for vocdoni/davinci-node (BN254 Groth16 hot path).
 
 The product is the C-ABI shared library ``csrc/libdvn_prover.so`` (see ``include/dvn_prover.h``); the Go shim a
-maintainer adds next to ``prover/prover_gpu.go`` binds it through cgo (INTEGRATION.md).  This Python package is
+maintainer adds next to ``prover/prover_gpu.go`` binds it through cgo.  This Python package is
 the ctypes harness over the same C-ABI that tests and bench.py use -- no arithmetic lives in Python, and there
 is NO CPU fallback: if the HIP library is missing or no GPU is visible, calls raise.
 

@@ -497,7 +497,7 @@ class Context:
 
 
 class R1CS:
-    """Host-side sparse R1CS handle (dvn_r1cs): the synthetic multiplication-gate instance of SURVEY.md §8d."""
+    """Host-side sparse R1CS handle (dvn_r1cs): the synthetic multiplication-gate instance."""
 
     def __init__(self, seed: int, n_constraints: int, n_public: int, curve: str = "bn254", n_committed: int = 0):
         self.L = load_library()
@@ -760,7 +760,7 @@ ImportedKey.last_stats = lambda self: _stats_json(self.ctx, self.h)
 
 
 class Bls12377:
-    """BLS12-377 entry points over an existing Context (SURVEY.md row f1).  Points: (n,12) G1 / (n,24) G2 uint64."""
+    """BLS12-377 entry points over an existing Context.  Points: (n,12) G1 / (n,24) G2 uint64."""
     PREFIX = "dvn_bls12377_"
 
     def _f(self, name):
@@ -834,12 +834,12 @@ class Bls12377:
 
 
 class Bls12381(Bls12377):
-    """BLS12-381 entry points (the blob-KZG curve, SURVEY.md row f3): same element sizes as BLS12-377."""
+    """BLS12-381 entry points (the blob-KZG curve): same element sizes as BLS12-377."""
     PREFIX = "dvn_bls12381_"
 
 
 class Bw6761:
-    """BW6-761 MSM entry points over an existing Context (SURVEY.md row f1).  Points: (n,24) uint64 for either
+    """BW6-761 MSM entry points over an existing Context.  Points: (n,24) uint64 for either
     group; scalars (n,6) uint64."""
 
     def __init__(self, ctx: Context):

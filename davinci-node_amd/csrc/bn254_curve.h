@@ -1,9 +1,9 @@
 // BN254 G1 / G2 group law for the MSM kernels: extended Jacobian (X, Y, ZZ, ZZZ) buckets + affine points.
 //
 // Stands in for gnark-crypto's g1JacExtended / g2JacExtended bucket arithmetic inside G1Jac.MultiExp /
-// G2Jac.MultiExp (SURVEY.md §8 row a12; reached from /root/reference/prover/prover_cpu.go:37).
-// Formulas: EFD madd-2008-s, add-2008-s, dbl-2008-s-1, mdbl-2008-s-1 (a = 0).  Affine infinity is (0,0)
-// (row a15); a bucket at infinity has ZZ == literal 0.
+// G2Jac.MultiExp (reached from /root/reference/prover/prover_cpu.go:37).
+// Formulas: EFD madd-2008-s, add-2008-s, dbl-2008-s-1, mdbl-2008-s-1 (a = 0).  Affine infinity is (0,0);
+// a bucket at infinity has ZZ == literal 0.
 #pragma once
 #include "bn254_field.h"
 
@@ -162,7 +162,7 @@ template <class F> struct Curve {
 
 typedef Curve<Fp> G1;
 typedef Curve<Fp2> G2;
-// BLS12-377 (voteverifier curve, SURVEY.md row f1): same a = 0 group law over 14-limb base-field elements
+// BLS12-377 (voteverifier curve): same a = 0 group law over 14-limb base-field elements
 typedef Curve<Fp377> G1_377;
 typedef Curve<Fp2_377> G2_377;
 typedef Curve<Fp381> G1_381;

@@ -3,7 +3,7 @@
 // Replaces, on the device, gnark-crypto's ecc/bn254/fp and ecc/bn254/fr Element arithmetic that
 // groth16.Prove (called at /root/reference/prover/prover_cpu.go:37, prover_gpu.go:33) spends its time in.
 //
-// Representation (MI355X-first, see DESIGN.md "Field arithmetic"):
+// Representation (MI355X-first):
 //   * 9 limbs x 29 bits in 32-bit VGPRs ("unsaturated"), Montgomery radix R' = 2^261.
 //     gfx950's only fast wide multiplier is v_mad_u64_u32 (32x32+64 -> 64, measured 4 cycles per wave64);
 //     32-bit add-with-carry chains need s_nop hazard padding on this target, and a saturated 8x32 CIOS
@@ -12,7 +12,7 @@
 //     with no carry handling at all: one v_mad_u64_u32 per partial product, nothing else in the hot loop.
 //   * Values are kept in [0, 2p) with limbs < 2^29 ("weak form").  mul output is < 1.03 p for inputs < 2p
 //     because R' / p > 2^7.
-//   * The external format is gnark's: 4 x u64 little-endian limbs, Montgomery R = 2^256 (SURVEY.md row a15).
+//   * The external format is gnark's: 4 x u64 little-endian limbs, Montgomery R = 2^256.
 //     ext -> internal multiplies by 2^5 (one Montgomery multiplication by 2^266 mod p), internal -> ext by
 //     2^-5.  Linear maps (NTT) skip both: an external Montgomery word is read as the internal form of
 //     x * 2^-5 and the scale factor commutes with the transform.

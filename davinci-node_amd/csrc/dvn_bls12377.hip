@@ -1,4 +1,4 @@
-// BLS12-377 instantiation (SURVEY.md §8 row f1): the curve of the voteverifier proofs (60 per batch,
+// BLS12-377 instantiation: the curve of the voteverifier proofs (60 per batch,
 // /root/reference/spec/params/params.go:21-27; GPU dispatch at /root/reference/prover/prover_gpu.go:36-43).
 // The same kernels as BN254, instantiated on 14-limb base-field elements (377 bits, external image 6 x u64,
 // R = 2^384), Fe2 with u^2 = -5 for G2, and the 253-bit scalar field (two-adicity 47, coset shift 22) for the NTT.

@@ -1,5 +1,5 @@
 // BLS12-381 instantiation: the fourth curve of the reference's GPU dispatch (/root/reference/prover/prover_gpu.go:45-50)
-// and the curve of the EIP-4844 blob commitment that precedes every state-transition proof (SURVEY.md §8 row f3: a
+// and the curve of the EIP-4844 blob commitment that precedes every state-transition proof (a
 // 4096-point G1 MSM over the KZG setup, /root/reference/crypto/blobs/blob.go:40-90, /root/reference/types/blobs.go:90-160).
 // Same kernels: 14-limb base field (381 bits, external image 6 x u64, R = 2^384), Fe2 with u^2 = -1 for G2, and the
 // 255-bit scalar field (two-adicity 32, coset shift 7) for the NTT.
@@ -90,7 +90,7 @@ extern "C" int32_t dvn_bls12381_groth16_pk_export_arrays(dvn_ctx* ctx, const dvn
     return groth16_pk_export_arrays<SuiteBls12381>(ctx, pk, which, out, cap_words, n_words);
 }
 
-// ---- blob KZG (EIP-4844 / EIP-7594) on this curve: SURVEY.md row f3 ----------------------------------------------------
+// ---- blob KZG (EIP-4844 / EIP-7594) on this curve ----------------------------------------------------
 #include "kzg_impl.h"
 // Pedersen commitment + PoK on this curve (gnark-crypto ecc/bls12-381/fr/pedersen ProvingKey.Commit / ProveKnowledge)
 extern "C" int32_t dvn_bls12381_pedersen_commit(dvn_ctx* ctx, const dvn_points* basis, const dvn_points* basis_exp_sigma, const uint64_t* values_mont,

@@ -1,4 +1,4 @@
-// BW6-761 instantiation (SURVEY.md §8 row f1): the curve of the aggregator proof (one per batch, 2^24-2^25
+// BW6-761 instantiation: the curve of the aggregator proof (one per batch, 2^24-2^25
 // constraints; /root/reference/spec/params/params.go:24, dispatch at /root/reference/prover/prover_gpu.go:36-43).
 // G1 (y^2 = x^3 - 1) and G2 (y^2 = x^3 + 4) both live over the 761-bit base field: 27 limbs of 29 bits
 // (R' = 2^783, external image 12 x u64 with R = 2^768); scalars are BLS12-377 base-field elements (377 bits,

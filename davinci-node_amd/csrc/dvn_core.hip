@@ -1,5 +1,5 @@
 // libdvn_prover.so -- context lifetime, memory helpers, error plumbing (include/dvn_prover.h).
-// Host side of the boundary described in SURVEY.md §8(b); stands where gnark's icicle backend stands behind
+// Host side of the C-ABI boundary; stands where gnark's icicle backend stands behind
 // /root/reference/prover/prover_gpu.go:24-61.
 #include <dlfcn.h>
 #include "dvn_internal.h"

@@ -117,7 +117,7 @@ extern "C" int32_t dvn_groth16_last_ms(const dvn_groth16_pk* pk, float* ms_h, fl
 
 
 // ------------------------------------------------------------------------------------------------------
-// Solidity ABI image of a proof (SURVEY.md row f4): /root/reference/solidity/solidity.go:29-73,85-116
+// Solidity ABI image of a proof: /root/reference/solidity/solidity.go:29-73,85-116
 // (uint256[8] proof, uint256[2] commitments, uint256[2] commitmentPok), every word big-endian, G2 coordinates in
 // EIP-197 order (A1 before A0).  Host only.
 // ------------------------------------------------------------------------------------------------------
@@ -147,7 +147,7 @@ extern "C" int32_t dvn_groth16_proof_abi_encode(const uint64_t proof[32], const 
 
 
 // ------------------------------------------------------------------------------------------------------
-// Pedersen commitment + proof of knowledge (SURVEY.md row a14: gnark-crypto ecc/bn254/fr/pedersen ProvingKey.Commit /
+// Pedersen commitment + proof of knowledge (gnark-crypto ecc/bn254/fr/pedersen ProvingKey.Commit /
 // ProveKnowledge, called from gnark's BSB22 commitment hint inside groth16.Prove): two G1 MSMs over the committed
 // wire values, against Basis and BasisExpSigma.  With a single commitment (statetransition has exactly one,
 // /root/reference/solidity/solidity.go:57-65) BatchProve's fold is the identity, so pok_out IS CommitmentPok.
@@ -162,8 +162,8 @@ extern "C" int32_t dvn_pedersen_commit(dvn_ctx* ctx, const dvn_points* basis, co
 
 // ------------------------------------------------------------------------------------------------------
 // Groth16 with ONE BSB22 commitment -- the statetransition shape: 8 public inputs + 1 commitment wire
-// (/root/reference/config/statetransition_vkey.sol:97-114, solidity/solidity.go:57-65).  gnark's Prove (SURVEY.md row a10,
-// steps (1)-(2)) computes, inside the solver's commitment hint, Commitment = MSM(pk.CommitmentKeys[0].Basis, committed wires),
+// (/root/reference/config/statetransition_vkey.sol:97-114, solidity/solidity.go:57-65).  gnark's Prove
+// computes, inside the solver's commitment hint, Commitment = MSM(pk.CommitmentKeys[0].Basis, committed wires),
 // derives the challenge that becomes the commitment wire, finishes the solve, and adds CommitmentPok =
 // MSM(BasisExpSigma, committed wires) (one commitment: BatchProve's fold is the identity).  The challenge is what the
 // reference's Solidity verifier recomputes: keccak256(C.x || C.y || publicCommitted) mod r (statetransition_vkey.sol:659-676).

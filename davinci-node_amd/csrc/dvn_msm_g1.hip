@@ -96,7 +96,7 @@ extern "C" int32_t dvn_msm_g1_batched(dvn_ctx* ctx, const dvn_points* pts, size_
 }
 
 // (window_bits, nwin, combine_bits) the library will use for an n-scalar MSM over this point set.  Expanded sets
-//  have pts-specific windows and combine_bits = 0: partial results of window ranges simply add up.
+// have pts-specific windows and combine_bits = 0: partial results of window ranges simply add up.
 extern "C" int32_t dvn_msm_plan_points(const dvn_points* pts, size_t n, uint32_t* window_bits, uint32_t* nwin, uint32_t* combine_bits) {
     if (!pts || !window_bits || !nwin || !combine_bits) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (use_expanded(pts, n)) { *window_bits = pts->expand_c; *nwin = pts->nexp; *combine_bits = 0; return DVN_OK; }

@@ -1,4 +1,4 @@
-// C++ mirror of the reference's `prover` package (SURVEY.md §8 rows a1-a9): the seam the sequencer calls.
+// C++ mirror of the reference's `prover` package: the seam the sequencer calls.
 //
 //   reference (Go)                                   here
 //   prover/config.go:16-26   UseGPUProver + init()   prover::UseGPUProver, prover::init_from_env()  (GPU_PROVER in {true,y,1,yes})

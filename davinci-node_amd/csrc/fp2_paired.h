@@ -1,4 +1,4 @@
-// Fp2 arithmetic with ONE COMPONENT PER LANE (DESIGN.md §4c): the even lane of a pair holds a0, the odd lane a1 of
+// Fp2 arithmetic with ONE COMPONENT PER LANE: the even lane of a pair holds a0, the odd lane a1 of
 // a0 + a1 u.  A G2 bucket accumulator then costs a lane what a G1 accumulator costs (4 x NL limbs of state instead of
 // 8 x NL), so the G2 hot loop runs fully inlined at the G1 kernel's occupancy instead of call-based at one wave per SIMD.
 // The partner's limbs arrive by DPP quad_perm [1,0,3,2] (one v_mov_dpp per limb, no LDS); both lanes execute the same

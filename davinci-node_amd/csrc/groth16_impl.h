@@ -1,5 +1,5 @@
-// Groth16 host orchestration over the device primitives, generic over the pairing curve (SURVEY.md rows a9/a10 and f1):
-// the C++ restatement of what the Go shim's hipGroth16Prove does (INTEGRATION.md §3), runnable without a Go toolchain.
+// Groth16 host orchestration over the device primitives, generic over the pairing curve:
+// the C++ restatement of what the Go shim's hipGroth16Prove does, runnable without a Go toolchain.
 //
 // Mirrors, step for step, gnark backend/groth16/<curve> prove.go `Prove` (called from
 // /root/reference/prover/prover_cpu.go:37 and, through the ICICLE wrapper, prover/prover_gpu.go:33-57) and setup.go
@@ -499,7 +499,7 @@ template <class SU> static int32_t groth16_setup(dvn_ctx* ctx, const dvn_r1cs* c
 // ------------------------------------------------------------------------------------------------------
 template <class SU> struct MsmResults { typename SU::H1::X mA, mB, mK, mZ; typename SU::H2::X mB2; };
 
-// Device part of a proof.  world == 1: the five full MSMs.  world > 1 (sharded proving, SURVEY.md §8e / BASELINE config 5):
+// Device part of a proof.  world == 1: the five full MSMs.  world > 1 (sharded proving):
 // this rank's slice of the ROWS of every (expanded) key set -- the partial results of all ranks add up to the MSMs; the
 // "solve" and computeH are replicated on every rank.  Caller holds ctx->mu.
 template <class SU> static int32_t groth16_device(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
@@ -663,7 +663,7 @@ template <class SU> static int32_t groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* p
     return DVN_OK;
 }
 
-// ---- keys that come from gnark: the in-memory arrays of a groth16.ProvingKey, handed over once (SURVEY.md §8b: "hold device
+// ---- keys that come from gnark: the in-memory arrays of a groth16.ProvingKey, handed over once ("hold device
 // handles in a side table keyed by PK pointer") -- the path a node takes with the proving keys it loads at
 // /root/reference/circuits/artifacts.go:391-406.  All point arrays are gnark affine Montgomery images; idxA / idxB / idxK list,
 // in order, the wires whose scalars go with A / B (= B2) / K (gnark drops the points at infinity of A and B -- InfinityA/B --
@@ -773,7 +773,7 @@ template <class SU> static int32_t groth16_pk_export_arrays(dvn_ctx* ctx, const 
     return fail(DVN_ERR_INVALID_ARG, "which must be 0..7");
 }
 // Prove from the solver's output (gnark: `solution.W`, `solution.A/B/C`): w = m wire values, a / b / c = len <= n values each.
-// Everything after the solve of row a10 runs here: computeH, the filtered MSMs on four lanes, blinding, assembly.
+// Everything after the R1CS solve of groth16.Prove runs here: computeH, the filtered MSMs on four lanes, blinding, assembly.
 template <class SU> static int32_t groth16_prove_solved(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b,
                                                         const uint64_t* c, size_t len, const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out) {
     typedef typename SU::FrC S;

@@ -1,7 +1,7 @@
 // Host-side finishing arithmetic with 4 x 64-bit limbs (Montgomery R = 2^256, i.e. gnark's own form).
 //
 // The tail of every MSM is a strictly sequential chain -- the MSB-first window combine of gnark-crypto's
-// MultiExp (`for j = last..0: acc = 2^c * acc + W_j`, SURVEY.md §8 row a12): ~256 doublings + 16 additions.
+// MultiExp (`for j = last..0: acc = 2^c * acc + W_j`): ~256 doublings + 16 additions.
 // One GPU wave needs ~5 us per group operation, a CPU core with 64x64->128 multiplies ~0.3 us, so the chain runs
 // here.  (The 29-bit device arithmetic also compiles for the host and is what tests/test_host_arith.py checks; this
 // file exists only because it is ~4x faster on a CPU.)  Inputs are the per-window sums as the device left them

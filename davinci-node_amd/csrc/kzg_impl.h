@@ -1,4 +1,4 @@
-// EIP-4844 / EIP-7594 blob KZG on the device (SURVEY.md §8 row f3) -- the step right before every state-transition proof:
+// EIP-4844 / EIP-7594 blob KZG on the device -- the step right before every state-transition proof:
 //   Blob.ComputeCommitment      /root/reference/types/blobs.go:88-95     (gethkzg.BlobToCommitment)
 //   Blob.ComputeProof(z)        /root/reference/types/blobs.go:120-133   (gethkzg.ComputeProof -> proof, claim)
 //   Blob.ComputeCellProofs      /root/reference/types/blobs.go:97-104    (gethkzg.ComputeCellProofs, 128 proofs)

@@ -218,7 +218,7 @@ static int32_t msm_windows_staged(dvn_ctx* ctx, MsmLane& L, const dvn_points* pt
     // row_table != NULL (batched only): the points are an expanded table, row w = 2^(c w) * P_i (n points per row, win_hi
     // rows).  The digit array has the same memory layout, but is read as ONE virtual window per vector with win_hi * n
     // entries whose point reference is the table position w * n + i: all windows of a vector share one bucket set, there
-    // is one bucket reduction per vector and no window combine (DESIGN.md §4b carried over to the batched path).
+    // is one bucket reduction per vector and no window combine (carried over to the batched path).
     const bool batched = d_batch_out != nullptr;
     const bool rowed = row_table != nullptr;
     if ((batch != 1 && !batched) || (rowed && !batched) || (batched && (win_lo != 0 || batch == 0 || !(flags & DVN_MSM_SCALARS_ON_DEVICE)))) return fail(DVN_ERR_INVALID_ARG, "batched MSM: all windows, device scalars, device output");

@@ -1,9 +1,9 @@
 // Pippenger MSM kernels for BN254 G1 / G2 on gfx950.
 //
-// Replaces gnark-crypto's G1Jac.MultiExp / G2Jac.MultiExp (SURVEY.md §8 row a12), which groth16.Prove calls
+// Replaces gnark-crypto's G1Jac.MultiExp / G2Jac.MultiExp, which groth16.Prove calls
 // five times per proof (/root/reference/prover/prover_cpu.go:37 -> gnark backend/groth16/bn254/prove.go).
 //
-// Pipeline (DESIGN.md "MSM"):
+// Pipeline:
 //   k_digits16/32 scalar (Montgomery) -> canonical -> signed c-bit digits for every window
 //   k_s1_* / k_s2_*   two-pass LDS-staged counting sort of (point ref | sign) by (window, bucket): both passes rank
 //                 with LDS atomics, reorder their 8192-entry tile in LDS and write runs
@@ -227,7 +227,7 @@ template <class S> __global__ void k_digits16_batched(const u32* __restrict__ sc
 }
 
 // ====================================================================================================================
-// Expanded point sets ("one bucket set", DESIGN.md §4b).  HBM is 288 GB, a proving key a few GB: at upload the table
+// Expanded point sets ("one bucket set").  HBM is 288 GB, a proving key a few GB: at upload the table
 // is widened to rows  row_w[i] = 2^(c w) * P_i,  w < nexp.  Every window of every scalar then lands in the SAME
 // 2^(c-1) buckets, so window size is no longer tied to the bucket-reduction cost: c = 20 gives 13 windows instead of
 // 16 (19 % fewer mixed additions), one bucket reduction instead of 16 and no window combine at all.
@@ -305,7 +305,7 @@ static __global__ __launch_bounds__(1024) void k_p1_scan(const u32* __restrict__
     if (t == T - 1) { bin_base[hb] = part[t]; totals[0] = part[t]; }
 }
 // ====================================================================================================================
-// Two-pass LDS-staged sort (DESIGN.md §4): the scattered 4-byte stores of a one-pass counting sort leave L2 as one
+// Two-pass LDS-staged sort: the scattered 4-byte stores of a one-pass counting sort leave L2 as one
 // request each (2^26 requests per 2^22-point MSM, ~1.3 ms), so both passes here reorder their tile in LDS first and
 // write RUNS: consecutive lanes store consecutive addresses.
 //   pass 1  tile = ST consecutive points of one window: bin = bucket >> lob (lb = nb >> lob bins per key-window),

@@ -6,7 +6,7 @@
 
 // per-field constants of gnark-crypto's fft.Domain: 2-adic root of unity (canonical words), its order, the coset shift
 template <class S> struct DomainConsts;
-template <> struct DomainConsts<FrCfg> {      // w_{2^28} = 5^((r-1)/2^28), FrMultiplicativeGen = 5 (SURVEY.md row a13)
+template <> struct DomainConsts<FrCfg> {      // w_{2^28} = 5^((r-1)/2^28), FrMultiplicativeGen = 5
     static constexpr u32 ADICITY = 28; static constexpr u64 COSET_GEN = 5; static constexpr int SUITE = 0;
     static const u64* root() { static const u64 r[4] = {0x9bd61b6e725b19f0ULL, 0x402d111e41112ed4ULL, 0x00e0a7eb8ef62abcULL, 0x2a3c09f0a58a7e85ULL}; return r; }
 };
@@ -155,7 +155,7 @@ template <class S> static int32_t ntt_device(dvn_ctx* ctx, const dvn_domain* d, 
     return DVN_OK;
 }
 
-// computeH core on device buffers (gnark prove.go computeH, SURVEY row a11): 3 x FFTInverse(DIF), 3 x FFT(DIT, coset),
+// computeH core on device buffers (gnark prove.go computeH): 3 x FFTInverse(DIF), 3 x FFT(DIT, coset),
 // pointwise (a*b - c) * den, FFTInverse(DIF, coset).  Result in da, bit-reversed.  Caller holds ctx->mu.
 template <class S> static int32_t compute_h_device(dvn_ctx* ctx, const dvn_domain* dom, u32* da, u32* db, u32* dc) {
     const size_t n = (size_t)1 << dom->log_n;

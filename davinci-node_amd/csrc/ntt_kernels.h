@@ -1,4 +1,4 @@
-// Radix-2 NTT over BN254 Fr on gfx950 with gnark-crypto's fft.Domain semantics (SURVEY.md §8 row a13):
+// Radix-2 NTT over BN254 Fr on gfx950 with gnark-crypto's fft.Domain semantics:
 //   DIF: natural in -> bit-reversed out, butterfly (a, b) -> (a + b, (a - b) * w)
 //   DIT: bit-reversed in -> natural out, butterfly (a, b) -> (a + b * w, a - b * w)
 //   FFT(OnCoset) pre-scales by g^i (bit-reversed index when DIT); FFTInverse post-scales by 1/n (and g^-i,

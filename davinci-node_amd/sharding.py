@@ -1,4 +1,4 @@
-"""One MSM / one proof shared between the GPUs of a node (SURVEY.md §8e; BASELINE.json north_star).
+"""One MSM / one proof shared between the GPUs of a node (BASELINE.json north_star).
 
 Every rank holds the whole device-resident point set and scalar vector and accumulates ITS SHARE of the Pippenger windows:
 for an expanded point set (row w = 2^(c w) P, all windows share one bucket set) the share is an equal range of the

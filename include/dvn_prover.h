@@ -1,13 +1,13 @@
 /* dvn_prover.h -- C-ABI of the MI355X-native prover backend (libdvn_prover.so).
  *
- * This is the drop-in boundary of SURVEY.md §8(b): the entry points a build-tagged Go file next to
- * /root/reference/prover/prover_gpu.go would bind through cgo (see INTEGRATION.md) in place of the ICICLE
+ * This is the drop-in boundary: the entry points a build-tagged Go file next to
+ * /root/reference/prover/prover_gpu.go would bind through cgo in place of the ICICLE
  * calls behind gpugroth16.Prove (prover/prover_gpu.go:33).  Every function is thread-safe, calls
  * hipSetDevice on entry (cgo calls arrive on arbitrary OS threads), never throws or aborts, and never keeps
  * a caller pointer after it returns (cgo pointer rule): host inputs are copied to the device before return
  * and outputs are written into caller buffers.
  *
- * Data formats are gnark-crypto's in-memory images (SURVEY.md §8 row a15), zero-copy from Go slices:
+ * Data formats are gnark-crypto's in-memory images, zero-copy from Go slices:
  *   fr.Element / fp.Element   4 x uint64 little-endian limbs, Montgomery form, R = 2^256
  *   G1Affine {X, Y}           8 x uint64, infinity = (0, 0)
  *   G2Affine {X.A0, X.A1, Y.A0, Y.A1}   16 x uint64
@@ -63,12 +63,12 @@ int32_t dvn_synchronize(dvn_ctx* ctx);
 
 /* ---- proving-key point arrays ------------------------------------------------------------------------ */
 /* Upload once per proving key (what icicle_bn254.ProvingKey's lazily uploaded device pointers hold,
- * SURVEY.md row a16; constructed at /root/reference/circuits/artifacts.go:634-637).
+ * constructed at /root/reference/circuits/artifacts.go:634-637).
  * xy_mont: N x 8 (G1) or N x 16 (G2) uint64. */
 int32_t dvn_points_upload_g1(dvn_ctx* ctx, const uint64_t* xy_mont, size_t n, dvn_points** out);
 int32_t dvn_points_upload_g2(dvn_ctx* ctx, const uint64_t* xy_mont, size_t n, dvn_points** out);
 /* Synthetic SRS generated on the device: P_i = [s0]G + i*[s1]G with (s0, s1) the first two Fr of the
- * SplitMix64 stream `seed` (SURVEY.md §8d config 2).  Bench/test input generator. */
+ * SplitMix64 stream `seed`.  Bench/test input generator. */
 int32_t dvn_points_synthetic_g1(dvn_ctx* ctx, uint64_t seed, size_t n, dvn_points** out);
 int32_t dvn_points_synthetic_g2(dvn_ctx* ctx, uint64_t seed, size_t n, dvn_points** out);
 /* (Re)build the set as an expanded table for window size window_bits in [11, 21] (row w = 2^(window_bits * w) * P_i,
@@ -77,7 +77,7 @@ int32_t dvn_points_synthetic_g2(dvn_ctx* ctx, uint64_t seed, size_t n, dvn_point
  * DVN_MSM_EXPAND_MAX_GB (16 GiB); DVN_MSM_EXPAND=0 turns the default off. */
 int32_t dvn_points_set_expanded(dvn_ctx* ctx, dvn_points* pts, uint32_t window_bits);
 /* Synthetic scalar vector written to DEVICE memory d_out (n x 4 uint64, gnark Montgomery form): kind 0 =
- * uniform mod r from SplitMix64 stream `seed`, kind 1 = the witness-like mixture of SURVEY.md §8d (40 % zero,
+ * uniform mod r from SplitMix64 stream `seed`, kind 1 = the witness-like mixture (40 % zero,
  * 25 % one, 25 % < 2^64, 10 % uniform).  Bench/test input generator. */
 int32_t dvn_scalars_synthetic(dvn_ctx* ctx, uint64_t seed, int kind, size_t n, void* d_out);
 /* Copy points [off, off+n) back to the host in gnark's affine Montgomery image. */
@@ -85,7 +85,7 @@ int32_t dvn_points_download(dvn_ctx* ctx, const dvn_points* pts, size_t off, siz
 size_t dvn_points_len(const dvn_points* pts);
 int32_t dvn_points_free(dvn_ctx* ctx, dvn_points* pts);
 
-/* ---- MultiExp (replaces gnark-crypto G1Jac.MultiExp / G2Jac.MultiExp, SURVEY.md row a12) -------------- */
+/* ---- MultiExp (replaces gnark-crypto G1Jac.MultiExp / G2Jac.MultiExp) -------------- */
 /* result = sum_{i<n} scalars[i] * points[off+i].  scalars_mont: n x 4 uint64 on the HOST.
  * out_jac: a valid Jacobian representative (this library returns the affine normal form with Z = 1, or
  * (1,1,0) for infinity); parity with gnark is defined after affine normalisation.
@@ -112,12 +112,12 @@ int32_t dvn_msm_g1_collect(dvn_ctx* ctx, int32_t ticket, uint64_t out_jac[12]);
 int32_t dvn_msm_g2_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars_mont,
                           uint32_t flags, int32_t* ticket);
 int32_t dvn_msm_g2_collect(dvn_ctx* ctx, int32_t ticket, uint64_t out_jac[24]);
-/* Window-sharded variant for multi-GPU (SURVEY.md §8e): this rank accumulates windows
+/* Window-sharded variant for multi-GPU: this rank accumulates windows
  * [win_lo, win_hi) of the `nwin` windows dvn_msm_plan reports and returns one extended-Jacobian point
  * (X, Y, ZZ, ZZZ; 16 x uint64 for G1) per window in window_sums; ranks exchange them (RCCL all-gather) and any rank
  * finishes with dvn_msm_combine_g1. */
 int32_t dvn_msm_plan(size_t n, uint32_t* window_bits, uint32_t* nwin);
-/* The plan for THIS point set: large sets are stored as an expanded table (row w = 2^(c w) * P, DESIGN.md §4b) whose
+/* The plan for THIS point set: large sets are stored as an expanded table (row w = 2^(c w) * P) whose
  * windows all share one bucket set; then combine_bits = 0 and dvn_msm_g1_windows returns the partial result of the
  * window range in slot 0 (remaining slots infinity): partial results add up, dvn_msm_combine_g1(.., window_bits = 0). */
 int32_t dvn_msm_plan_points(const dvn_points* pts, size_t n, uint32_t* window_bits, uint32_t* nwin, uint32_t* combine_bits);
@@ -142,7 +142,7 @@ int32_t dvn_msm_g1_share_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off,
 int32_t dvn_msm_g1_share_collect(dvn_ctx* ctx, int32_t ticket, uint64_t partial_jac[12]);
 int32_t dvn_msm_g1_sum(const uint64_t* jacs /* count x 12 */, uint32_t count, uint64_t out_jac[12]);
 
-/* ---- fr/fft (replaces gnark-crypto fft.Domain, SURVEY.md row a13) ------------------------------------- */
+/* ---- fr/fft (replaces gnark-crypto fft.Domain) ------------------------------------- */
 #define DVN_DIF 0
 #define DVN_DIT 1
 int32_t dvn_ntt_domain(dvn_ctx* ctx, uint32_t log_n, dvn_domain** out);      /* fft.NewDomain(1 << log_n) */
@@ -153,15 +153,15 @@ int32_t dvn_ntt_domain_free(dvn_ctx* ctx, dvn_domain* dom);
 int32_t dvn_ntt(dvn_ctx* ctx, const dvn_domain* dom, uint64_t* data, int inverse, int decimation, int on_coset,
                 uint32_t flags);
 
-/* ---- groth16 computeH (SURVEY.md row a11) -------------------------------------------------------------- */
+/* ---- groth16 computeH -------------------------------------------------------------- */
 /* a, b, c: len <= n elements each (host, or device with DVN_NTT_DATA_ON_DEVICE); h_out: n elements, the
  * coefficients of h in bit-reversed order exactly as gnark's computeH leaves them. */
 int32_t dvn_groth16_compute_h(dvn_ctx* ctx, const dvn_domain* dom, const uint64_t* a, const uint64_t* b,
                               const uint64_t* c, size_t len, uint64_t* h_out, uint32_t flags);
 
-/* ---- Groth16 orchestration (SURVEY.md rows a9, a10): what the Go shim's hipGroth16Prove does, in C++ ------------- */
+/* ---- Groth16 orchestration: what the Go shim's hipGroth16Prove does, in C++ ------------- */
 /* A sparse R1CS  (A w) o (B w) = (C w)  stands in for gnark's constraint.ConstraintSystem.  dvn_r1cs_synthetic builds
- * the seeded multiplication-gate instance of SURVEY.md §8d config 5 (rows (w[l1] + k w[l2]) * w[r] = w[o], wire 0 =
+ * the seeded multiplication-gate instance (rows (w[l1] + k w[l2]) * w[r] = w[o], wire 0 =
  * constant 1, wires 1..n_public-1 public) together with its satisfying wire assignment.  Host only. */
 typedef struct dvn_r1cs dvn_r1cs;
 typedef struct dvn_groth16_pk dvn_groth16_pk;
@@ -211,7 +211,7 @@ int32_t dvn_groth16_last_stats_json(const dvn_groth16_pk* pk, char* buf, size_t 
  * "solve", computeH -- the B2, A, B1 and K MSMs already run beside it on the four lanes), ms_msm = from there to the last MSM, total */
 int32_t dvn_groth16_last_ms(const dvn_groth16_pk* pk, float* ms_h, float* ms_msm, float* ms_total);
 
-/* Pedersen commitment and its proof of knowledge (SURVEY.md row a14; gnark-crypto fr/pedersen ProvingKey.Commit /
+/* Pedersen commitment and its proof of knowledge (gnark-crypto fr/pedersen ProvingKey.Commit /
  * ProveKnowledge, reached from the BSB22 commitment hint of groth16.Prove): commitment = MSM(Basis, values),
  * pok = MSM(BasisExpSigma, values); with one commitment (statetransition) the BatchProve fold is the identity.
  * values: n x 4 uint64 Montgomery (host; device pointer if flags & 1).  Outputs: G1Affine images. */
@@ -219,12 +219,12 @@ int32_t dvn_pedersen_commit(dvn_ctx* ctx, const dvn_points* basis, const dvn_poi
                             const uint64_t* values_mont, size_t n, uint32_t flags,
                             uint64_t commitment_out[8], uint64_t pok_out[8]);
 /* Solidity ABI image (uint256[8], uint256[2], uint256[2]) of a proof, as /root/reference/solidity/solidity.go:29-73,
- * 85-116 builds it for the on-chain verifier (SURVEY.md row f4): big-endian words, G2 coordinates A1 before A0.
+ * 85-116 builds it for the on-chain verifier: big-endian words, G2 coordinates A1 before A0.
  * commitment / commitment_pok: G1Affine images or NULL (zeros).  Host only. */
 int32_t dvn_groth16_proof_abi_encode(const uint64_t proof[32], const uint64_t commitment[8], const uint64_t commitment_pok[8],
                                      uint8_t out[384]);
 
-/* ---- mirror of the reference's `prover` package (SURVEY.md rows a1-a9; csrc/dvn_prover_pkg.hip) --------------------- */
+/* ---- mirror of the reference's `prover` package (csrc/dvn_prover_pkg.hip) --------------------- */
 /* Same control flow as /root/reference/prover/prover_gpu.go:66-123: Prove -> prover func (SetProver seam) ->
  * defaultProver: if UseGPUProver (env GPU_PROVER in {true,y,1,yes}, prover/config.go:18-26) try the GPU and on ANY
  * error print "GPU proving failed (<err>), falling back to CPU" and run the CPU prover.  The CPU prover is the
@@ -253,7 +253,7 @@ int32_t dvn_prover_prove(dvn_ctx* ctx, int32_t curve, const dvn_r1cs* ccs, dvn_g
                          const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out);
 int32_t dvn_prover_setup(dvn_ctx* ctx, const dvn_r1cs* ccs, uint64_t seed, dvn_groth16_pk** pk);   /* prover.Setup */
 
-/* ---- BLS12-377 (SURVEY.md row f1) ------------------------------------------------------------------------------------ */
+/* ---- BLS12-377 ------------------------------------------------------------------------------------ */
 /* The voteverifier's curve (/root/reference/spec/params/params.go:21-27; reference GPU dispatch prover/prover_gpu.go:36-43).
  * Same kernels, instantiated on 377-bit base-field elements.  gnark images: fp.Element 6 x uint64 (R = 2^384),
  * fr.Element 4 x uint64, G1Affine 12 x uint64, G2Affine 24 x uint64 (E2 = A0 + A1 u, u^2 = -5), G1Jac 18, G2Jac 36.
@@ -284,7 +284,7 @@ int32_t dvn_bls12377_groth16_setup(dvn_ctx* ctx, const dvn_r1cs* cs, uint64_t se
 int32_t dvn_bls12377_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
                                    const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[48]);
 
-/* ---- BLS12-381 (SURVEY.md row f3) ------------------------------------------------------------------------------------ */
+/* ---- BLS12-381 ------------------------------------------------------------------------------------ */
 /* The fourth curve of the reference's GPU dispatch (/root/reference/prover/prover_gpu.go:45-50) and the curve of the
  * EIP-4844 blob commitment computed before every state-transition proof: a 4096-point G1 MSM over the KZG setup in
  * Lagrange form (/root/reference/crypto/blobs/blob.go:40-90, types/blobs.go:90-160).  Element images have the sizes of
@@ -310,7 +310,7 @@ int32_t dvn_bls12381_groth16_setup(dvn_ctx* ctx, const dvn_r1cs* cs, uint64_t se
 int32_t dvn_bls12381_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
                                    const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[48]);
 
-/* ---- BW6-761 (SURVEY.md row f1) -------------------------------------------------------------------------------------- */
+/* ---- BW6-761 -------------------------------------------------------------------------------------- */
 /* The aggregator's curve (/root/reference/spec/params/params.go:24; one proof per batch; reference GPU dispatch
  * prover/prover_gpu.go:52-57).  G1 (y^2 = x^3 - 1) and G2
  * (y^2 = x^3 + 4) both live over the 761-bit base field, so one entry point serves both; `group` (1 or 2) is recorded in
@@ -340,7 +340,7 @@ int32_t dvn_bw6761_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_
                                  const uint64_t r_mont[6], const uint64_t s_mont[6], uint64_t proof_out[72]);
 
 /* ---- Groth16 with one BSB22 commitment: the statetransition shape (8 public inputs + 1 commitment wire,
- * /root/reference/config/statetransition_vkey.sol:97-114; gnark Prove steps (1)-(2) of SURVEY.md row a10, row a14).
+ * /root/reference/config/statetransition_vkey.sol:97-114; gnark Prove's commitment steps and fr/pedersen).
  * dvn_r1cs_synthetic_committed: as dvn_r1cs_synthetic plus a commitment wire after the n_public public wires and
  * n_committed committed private wires; dvn_r1cs_info then reports n_public + 1 public wires.  dvn_groth16_setup builds
  * the commitment key (Basis = K / gamma over the committed wires, BasisExpSigma = sigma * Basis).
@@ -348,12 +348,12 @@ int32_t dvn_bw6761_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_
  * keccak256(C.x || C.y || publicCommitted) mod r that the reference's Solidity verifier recomputes
  * (statetransition_vkey.sol:659-676), the completion of the witness, then the proof as dvn_groth16_prove.
  * Together with dvn_groth16_proof_abi_encode this yields the calldata of solidity/solidity.go:85-116. */
-/* ---- gnark's own proving key (SURVEY.md §8b: device handles in a side table keyed by the PK pointer) --------------------
+/* ---- gnark's own proving key (device handles in a side table keyed by the PK pointer) --------------------
  * dvn_groth16_pk_import takes the in-memory arrays of a *groth16_bn254.ProvingKey as the node loads it
  * (/root/reference/circuits/artifacts.go:391-406; zero-copy from the Go slices, copied to HBM before return): G1.A / G1.B /
  * G1.K / G1.Z / G2.B as gnark affine Montgomery images, the wire indices that go with A, B (= G2.B) and K in order (gnark
  * drops InfinityA / InfinityB points and keeps K for the private, non-committed wires), and the five key constants.
- * dvn_groth16_prove_solved then runs everything of groth16.Prove that follows the solver (row a10 steps (3)-(7)): w = all
+ * dvn_groth16_prove_solved then runs everything of groth16.Prove that follows the solver: w = all
  * wire values, a / b / c = the solver's constraint evaluations (len <= 2^log_n each, zero padded here). */
 typedef struct dvn_groth16_key_arrays {
     uint32_t log_n;              /* domain size 2^log_n */
@@ -404,7 +404,7 @@ int32_t dvn_bw6761_groth16_prove_solved(dvn_ctx* ctx, dvn_groth16_pk* pk, const 
                                         const uint64_t* c, size_t len, const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out);
 int32_t dvn_bw6761_groth16_pk_export_arrays(dvn_ctx* ctx, const dvn_groth16_pk* pk, int which, uint64_t* out, size_t cap_words, size_t* n_words);
 
-/* ---- gnark's artifact FILES (SURVEY.md row f2) ---------------------------------------------------------------------
+/* ---- gnark's artifact FILES ---------------------------------------------------------------------
  * The node keeps proving keys as sha256-named files written by cmd/circuit-compile with pk.WriteTo
  * (/root/reference/cmd/circuit-compile/main.go:507-513) and loads them with pk.UnsafeReadFrom
  * (/root/reference/circuits/artifacts.go:391-406, hash check :123-133).  dvn_groth16_pk_load_file reads the same bytes
@@ -437,7 +437,7 @@ int32_t dvn_groth16_prove_committed(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint
                                     uint64_t commitment_out[8], uint64_t pok_out[8], uint64_t challenge_out[4]);
 int32_t dvn_keccak256(const uint8_t* data, size_t len, uint8_t out[32]);     /* host only: Solidity's keccak256 */
 
-/* ---- Blob KZG on BLS12-381 (EIP-4844 / EIP-7594; SURVEY.md row f3) ------------------------------------------------
+/* ---- Blob KZG on BLS12-381 (EIP-4844 / EIP-7594) ------------------------------------------------
  * The step before every state-transition proof, /root/reference/crypto/blobs/blob.go:40-90 (BlobEvalData.Set):
  *   dvn_kzg_blob_to_commitment   replaces Blob.ComputeCommitment   /root/reference/types/blobs.go:88-95
  *   dvn_kzg_compute_proof        replaces Blob.ComputeProof        /root/reference/types/blobs.go:120-133  (proof, claim y)

@@ -2,14 +2,14 @@
  *
  * A plain-C restatement of what prover/prover_cpu.go:37 (groth16.Prove) spends its time in, following the
  * published algorithms of the un-vendored modules pinned in /root/reference/go.mod:15-16:
- *   - gnark-crypto ecc/bn254 multiexp.go  -> orc_msm_g1 / orc_msm_g2        
- *   - gnark-crypto ecc/bn254/fr/fft       -> orc_ntt                         (row a13)
- *   - gnark backend/groth16/bn254 prove.go computeH -> orc_compute_h         (row a11)
+ *   - gnark-crypto ecc/bn254 multiexp.go  -> orc_msm_g1 / orc_msm_g2
+ *   - gnark-crypto ecc/bn254/fr/fft       -> orc_ntt
+ *   - gnark backend/groth16/bn254 prove.go computeH -> orc_compute_h
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
- * PARITY UNPINNED by reference vectors (none exist, SURVEY.md §8c); pinned against oracle/bn254_py.py and
+ * PARITY UNPINNED by reference vectors (none exist); pinned against oracle/bn254_py.py and
  * the reference's curve constants by tests/test_oracle.py.
  *
- * All field elements cross this API as 4 x u64 little-endian Montgomery limbs (row a15) unless a parameter
+ * All field elements cross this API as 4 x u64 little-endian Montgomery limbs unless a parameter
  * says "canonical".
  */
 #include <stdio.h>
@@ -207,7 +207,7 @@ int orc_msm_g2(const u64* points, size_t n_points, const u64* scalars_mont, size
     return 0;
 }
 
-/* ------------------------------------------------------------------ fr/fft Domain (row a13) */
+/* ------------------------------------------------------------------ fr/fft Domain */
 static const u64 FR_ROOT_2_28_MONT[4] = {0x636e735580d13d9cULL, 0xa22bf3742445ffd6ULL, 0x56452ac01eb203d8ULL, 0x1860ef942963f9e7ULL};
 
 typedef struct {
@@ -325,7 +325,7 @@ double orc_ntt_roundtrip_seconds(u64* data, int log_n, int reps, int nthreads) {
     return t1 - t0;
 }
 
-/* gnark groth16 computeH (row a11): a, b, c have `len` <= n elements; h_out gets n elements (bit-reversed) */
+/* gnark groth16 computeH: a, b, c have `len` <= n elements; h_out gets n elements (bit-reversed) */
 int orc_compute_h(const u64* a_in, const u64* b_in, const u64* c_in, size_t len, int log_n, u64* h_out, int nthreads) {
     size_t n = (size_t)1 << log_n;
     if (len > n) return -1;
@@ -351,7 +351,7 @@ int orc_compute_h(const u64* a_in, const u64* b_in, const u64* c_in, size_t len,
 
 int orc_num_threads(void) { return omp_get_max_threads(); }
 
-/* ------------------------------------------------------------------ synthetic Groth16 checker (row a10) */
+/* ------------------------------------------------------------------ synthetic Groth16 checker */
 /* Restates oracle/bn254_py.py SyntheticR1CS + groth16_setup's trapdoor + groth16_expected_from_trapdoor:
  * the proof a correct prover must output for injected (r, s), from O(n) field work and three fixed-base
  * scalar multiplications -- no MSM, no NTT, so it is independent of everything it checks. */

@@ -1,9 +1,9 @@
 /* Curve-group template for the CPU oracle (TEST INFRASTRUCTURE).  Included twice by bn254_cpu.c:
  *   G1 over Fp   (FE = fe,  F(op) = fp_op,  ECN(x) = g1_x)
  *   G2 over Fp2  (FE = fe2, F(op) = fp2_op, ECN(x) = g2_x)
- * y^2 = x^3 + b, a = 0.  Affine infinity = (0,0) as in gnark-crypto's G1Affine/G2Affine (SURVEY.md row a15).
+ * y^2 = x^3 + b, a = 0.  Affine infinity = (0,0) as in gnark-crypto's G1Affine/G2Affine.
  * Buckets use extended Jacobian (X, Y, ZZ, ZZZ) like gnark-crypto's g1JacExtended (ecc/bn254/g1.go, EFD
- * madd-2008-s / add-2008-s / dbl-2008-s-1), and the MSM follows ecc/bn254/multiexp.go's structure (row a12):
+ * madd-2008-s / add-2008-s / dbl-2008-s-1), and the MSM follows ecc/bn254/multiexp.go's structure:
  * signed c-bit digits, one task per window, running-sum bucket reduction, MSB-first window combine.
  * The batch-affine bucket variant gnark uses for c >= 10 computes the same group element and is not restated.
  */

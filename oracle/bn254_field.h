@@ -2,7 +2,7 @@
  *
  * Restates ecc/bn254/fp and ecc/bn254/fr of github.com/consensys/gnark-crypto
  * v0.19.3-0.20260126145145-b5cf053fbc34 (/root/reference/go.mod:16, un-vendored): Element = [4]uint64
- * little-endian limbs in Montgomery form with R = 2^256 (SURVEY.md §8 row a15).  Portable C with
+ * little-endian limbs in Montgomery form with R = 2^256.  Portable C with
  * unsigned __int128 instead of gnark-crypto's amd64 assembly.  Checked against oracle/bn254_py.py and the
  * reference constants of config/statetransition_vkey.sol:42-59 by tests/test_oracle.py.
  * PARITY UNPINNED beyond those constants -- see oracle/bn254_py.py header.

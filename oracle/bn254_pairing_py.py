@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE ONLY -- BN254 optimal-ate pairing and the reference's Groth16 verifier, in Python big ints.
 
-Why: every prover test of the reference is a prove -> verify round trip (SURVEY.md §8c), the strongest one through the
+Why: every prover test of the reference is a prove -> verify round trip, the strongest one through the
 generated Solidity verifier on a simulated EVM (circuits/test/statetransition/statetransition_test.go:198-249).  That
 verifier is IN THE TREE: /root/reference/config/statetransition_vkey.sol.  `verify_proof_sol` below restates its
 `verifyProof` (lines 654-744) + `publicInputMSM` (393-520) step by step over the EVM precompile semantics

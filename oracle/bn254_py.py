@@ -4,7 +4,7 @@ TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is part of the product: onl
 ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it,
 and only as the checker.  The product path is the HIP library behind ``include/dvn_prover.h``.
 
-PARITY UNPINNED (SURVEY.md §8c): the arithmetic of this path lives in un-vendored Go modules
+PARITY UNPINNED: the arithmetic of this path lives in un-vendored Go modules
 (``/root/reference/go.mod:15-16`` -- gnark v0.14.1-0.20260126121332-407111efab55 and gnark-crypto
 v0.19.3-0.20260126145145-b5cf053fbc34), there is no Go toolchain here, and the reference's own tests hold
 no MSM / NTT / proof-byte vectors (every prover test is prove->verify,
@@ -39,7 +39,7 @@ G2_GEN = (
     (8495653923123431417604973247489272438418190587263600148770280649306958101930,
      4082367875863433681332203403145435568316851327593401208105741076214120093531),
 )
-FR_MULT_GEN = 5                      # fft.Domain.FrMultiplicativeGen for BN254 (SURVEY.md §8 row a13)
+FR_MULT_GEN = 5                      # fft.Domain.FrMultiplicativeGen for BN254
 FR_TWO_ADICITY = 28
 FR_ROOT_2_28 = 19103219067921713944291392827692070036145651957329286315305642004821462161904
 assert pow(FR_MULT_GEN, (R - 1) >> FR_TWO_ADICITY, R) == FR_ROOT_2_28
@@ -47,7 +47,7 @@ MASK64 = (1 << 64) - 1
 
 
 # --------------------------------------------------------------------------------------------------------
-# Montgomery helpers and limb (de)serialisation (SURVEY.md §8 row a15)
+# Montgomery helpers and limb (de)serialisation
 # --------------------------------------------------------------------------------------------------------
 def to_mont(x: int, mod: int) -> int:
     return (x << 256) % mod
@@ -116,7 +116,7 @@ def fr_at(seed: int, i: int) -> int:
 
 
 def witness_like_scalar(seed: int, i: int) -> int:
-    """'S-witness' mix of SURVEY.md §8d: 40 % zero, 25 % one, 25 % < 2^64, 10 % uniform (canonical)."""
+    """'S-witness' mix: 40 % zero, 25 % one, 25 % < 2^64, 10 % uniform (canonical)."""
     sel = splitmix_at(seed ^ 0x5EED5EED5EED5EED, i) % 100
     if sel < 40:
         return 0
@@ -268,7 +268,7 @@ def ec_mul(F, pt, k: int):
 
 
 def ec_msm(F, points, scalars):
-    """Sum_i scalars[i] * points[i], the definition gnark-crypto's MultiExp must agree with (row a12)."""
+    """Sum_i scalars[i] * points[i], the definition gnark-crypto's MultiExp must agree with."""
     if len(points) != len(scalars):
         raise ValueError("len(points) != len(scalars)")       # same error condition as MultiExp
     acc = None
@@ -339,7 +339,7 @@ def synthetic_g2_points(seed: int, n: int):
 
 
 # --------------------------------------------------------------------------------------------------------
-# fr/fft Domain (row a13).  All vectors are canonical integers mod R here; the Montgomery image is a
+# fr/fft Domain.  All vectors are canonical integers mod R here; the Montgomery image is a
 # serialisation detail handled by to_mont/limbs.
 # --------------------------------------------------------------------------------------------------------
 def bitrev(i: int, log_n: int) -> int:
@@ -363,7 +363,7 @@ class Domain:
         self.coset = FR_MULT_GEN
         self.coset_inv = pow(FR_MULT_GEN, -1, R)
 
-    # butterflies exactly as in SURVEY.md row a13
+    # butterflies exactly as gnark-crypto's fft.Domain orders them
     def _dif(self, a, w):
         n = self.n
         half = n >> 1
@@ -416,7 +416,7 @@ def naive_dft(a, w):
 
 
 def compute_h(a, b, c, domain: Domain):
-    """gnark groth16 computeH (row a11).  Returns n values, coefficients of h in bit-reversed order."""
+    """gnark groth16 computeH.  Returns n values, coefficients of h in bit-reversed order."""
     n = domain.n
     a = list(a) + [0] * (n - len(a))
     b = list(b) + [0] * (n - len(b))
@@ -433,7 +433,7 @@ def compute_h(a, b, c, domain: Domain):
 
 
 # --------------------------------------------------------------------------------------------------------
-# Synthetic Groth16 instance with a known trapdoor (row a10)
+# Synthetic Groth16 instance with a known trapdoor
 # --------------------------------------------------------------------------------------------------------
 class SyntheticR1CS:
     """n_c constraints (w[l] + k*w[l2]) * w[r] = w[o]; wire 0 is the constant 1, wires 1..n_pub-1 public.
@@ -494,7 +494,7 @@ def lagrange_at(domain: Domain, tau: int):
 
 
 def groth16_setup(cs: SyntheticR1CS, seed: int):
-    """Returns (pk, trapdoor).  pk mirrors gnark's bn254 ProvingKey fields used by Prove (row a10):
+    """Returns (pk, trapdoor).  pk mirrors gnark's bn254 ProvingKey fields used by Prove:
     G1.{Alpha,Beta,Delta,A,B,K,Z}, G2.{Beta,Delta,B}.  No infinity filtering (InfinityA/B empty)."""
     rng = SplitMix64(seed)
     tau, alpha, beta, gamma, delta = (rng.next_fr() or 1 for _ in range(5))
@@ -530,7 +530,7 @@ def groth16_setup(cs: SyntheticR1CS, seed: int):
 
 
 def groth16_prove(cs: SyntheticR1CS, pk, r: int, s: int):
-    """gnark groth16 Prove steps (3)-(7) of row a10 with injected blinding (r, s)."""
+    """gnark groth16 Prove after the solver (computeH, the five MSMs, blinding) with injected blinding (r, s)."""
     dom = pk["domain"]
     a, b, c = cs.abc()
     h = compute_h(a, b, c, dom)
@@ -566,7 +566,7 @@ def groth16_expected_from_trapdoor(cs: SyntheticR1CS, trap, dom: Domain, r: int,
 
 
 # ------------------------------------------------------------------------------------------------------
-# BSB22 commitment (SURVEY.md rows a10 steps (1)-(2), a14): the statetransition circuit has exactly one
+# BSB22 commitment: the statetransition circuit has exactly one
 # (/root/reference/solidity/solidity.go:57-65; 8 public inputs + 1 commitment wire = PUB_0..PUB_8,
 # /root/reference/config/statetransition_vkey.sol:97-114).  What the reference tree itself pins:
 #   challenge  = keccak256(C.x || C.y || publicCommitted...) mod r            statetransition_vkey.sol:659-676

@@ -1,6 +1,6 @@
 """Curve-generic big-integer oracle (TEST INFRASTRUCTURE ONLY; see oracle/bn254_py.py header for the rules).
 
-Extends the BN254 oracle to the other curves the reference proves on (SURVEY.md §8 row f1): BLS12-377
+Extends the BN254 oracle to the other curves the reference proves on: BLS12-377
 (voteverifier, `/root/reference/spec/params/params.go:21-27`; GPU dispatch at `prover/prover_gpu.go:36-43`).
 Same conventions as gnark-crypto: Element = little-endian u64 limbs in Montgomery form with R = 2^(64 * limbs)
 (4 limbs for the 253/254-bit fields, 6 for BLS12-377's 377-bit base field); E2 = a0 + a1*u with u^2 = -BETA;
@@ -279,7 +279,7 @@ BLS12_377.g2_gen = (
 
 _P381 = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
 _R381 = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
-# BLS12-381 (blob KZG; prover_gpu.go:45-50): y^2 = x^3 + 4, twist y^2 = x^3 + 4(1 + u), u^2 = -1, Fr generator 7
+# BLS12-381 (blob KZG, prover_gpu.go:45-50): y^2 = x^3 + 4, twist y^2 = x^3 + 4(1 + u), u^2 = -1, Fr generator 7
 BLS12_381 = Suite(
     "bls12-381", _P381, _R381, b_g1=4, beta=1, b_g2=(4, 4),
     g1_gen=(0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB,

@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE ONLY -- CPU restatement (Python big ints) of the EIP-4844 / EIP-7594 blob KZG operations the
-reference performs before every state-transition proof (SURVEY.md §8 row f3):
+reference performs before every state-transition proof:
 
   Blob.ComputeCommitment          /root/reference/types/blobs.go:88-95      (gethkzg.BlobToCommitment)
   Blob.ComputeProof(z)            /root/reference/types/blobs.go:120-133    (gethkzg.ComputeProof -> proof, claim y)

@@ -1,6 +1,6 @@
 """Generates the committed golden vectors from the pure-Python big-int oracle (oracle/bn254_py.py).
 
-The reference holds no MSM/NTT/proof vectors (SURVEY.md §8c "parity unpinned"), so these pin the C oracle and
+The reference holds no MSM/NTT/proof vectors, so these pin the C oracle and
 the HIP library against the independent Python restatement.  Deterministic: rerunning reproduces the files.
 """
 import json, os, sys

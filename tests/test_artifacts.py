@@ -1,4 +1,4 @@
-"""gnark proving-key artifact reader (SURVEY.md row f2): the binary layout `pk.WriteTo` produces
+"""gnark proving-key artifact reader: the binary layout `pk.WriteTo` produces
 (/root/reference/cmd/circuit-compile/main.go:507-513) and `pk.UnsafeReadFrom` consumes
 (/root/reference/circuits/artifacts.go:391-406), read by csrc/dvn_artifacts.hip into a device-resident key.
 

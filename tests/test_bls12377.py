@@ -1,4 +1,4 @@
-"""BLS12-377 (the voteverifier curve) and BLS12-381 (row f3; blob KZG, the fourth curve of
+"""BLS12-377 (the voteverifier curve) and BLS12-381 (blob KZG, the fourth curve of
 prover_gpu.go's dispatch): the same HIP kernels instantiated on 14-limb base-field elements, checked against the
 curve-generic Python oracle (oracle/curves_py.py).  Parity unpinned by the reference (no vectors); the oracle's
 constants are cross-checked in test_bls12377_constants / test_bls12381_constants."""

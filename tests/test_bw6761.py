@@ -1,4 +1,4 @@
-"""BW6-761 (SURVEY.md row f1; the aggregator curve): the MSM kernels instantiated on 27-limb base-field elements and
+"""BW6-761 (the aggregator curve): the MSM kernels instantiated on 27-limb base-field elements and
 377-bit scalars, checked against the big-integer oracle (oracle/curves_py.py Bw6761).  Parity unpinned by the
 reference (no vectors); the constants are cross-checked in test_bw6761_constants."""
 import ctypes as C

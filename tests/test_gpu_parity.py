@@ -1,5 +1,5 @@
 """Parity of the HIP path (through the C-ABI, include/dvn_prover.h) against the oracle.  Bit-exact everywhere:
-this is integer work.  MSM results are compared after affine normalisation (SURVEY.md §8b)."""
+this is integer work.  MSM results are compared after affine normalisation."""
 import numpy as np
 import pytest
 
@@ -105,7 +105,7 @@ def test_msm_g1_linearity_and_window_sharding(ctx, orc, opy):
     ab = np.array([orc.fr_add(a[i], b[i]) for i in range(n)], dtype=np.uint64)
     ra, rb, rab = (aff1(orc, ctx.msm_g1(pts, s)) for s in (a, b, ab))
     assert (orc.g1_add(ra, rb) == rab).all()
-    # window-sharded evaluation (SURVEY.md §8e): any split of the windows recombines to the same point
+    # window-sharded evaluation: any split of the windows recombines to the same point
     _, nwin, cb = ctx.msm_plan_points(pts, n)
     for cuts in ([0, nwin], [0, nwin // 2, nwin], [0, 1, 5, nwin]):
         parts = [ctx.msm_g1_windows(pts, a, lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:])]
@@ -214,7 +214,7 @@ def test_window_sharded_pipeline_single_process(ctx, orc, pkg):
 
 
 def test_thread_safety_concurrent_callers(ctx, orc):
-    """gnark issues its MSMs from concurrent goroutines and cgo calls arrive on arbitrary OS threads (SURVEY.md §8b):
+    """gnark issues its MSMs from concurrent goroutines and cgo calls arrive on arbitrary OS threads:
     four threads hammer one context with MSMs and NTTs; every result must still be bit-exact."""
     import threading
     n = 6000
@@ -272,7 +272,7 @@ def test_msm_g2_vs_oracle(ctx, orc, n):
 
 
 def test_msm_g2_every_bucket_heavy(ctx, orc):
-    """Regression for the out-of-range LDS addressing of call-based reductions (DESIGN.md §4): with 11-bit windows on 2^16
+    """Regression for the out-of-range LDS addressing of call-based reductions: with 11-bit windows on 2^16
     points every one of the 1024 buckets spans ~96 segments, so each block of k_fix_heavy iterates twice.  Plain and expanded
     evaluation must agree (and with the oracle on a prefix)."""
     n = 1 << 16

@@ -1,4 +1,4 @@
-"""Groth16 orchestration (SURVEY.md rows a9/a10): the library's Setup + Prove on the synthetic statetransition-shaped
+"""Groth16 orchestration: the library's Setup + Prove on the synthetic statetransition-shaped
 instance against the trapdoor identity -- the proof must equal [alpha + sum w_i A_i(tau) + r delta]G1 etc. bit for bit
 for the injected (r, s).  The checker (oracle) uses no MSM and no NTT."""
 import numpy as np
@@ -56,7 +56,7 @@ def test_groth16_trapdoor_identity(ctx, pkg, opy, orc, n_constraints, n_public):
         got = key.prove(cs.witness(), mont(opy, r), mont(opy, s))
         for k in ("Ar", "Bs", "Krs"):
             assert (got[k] == want[k]).all(), (k, r, s)
-    # device-resident witness (HBM hand-off, SURVEY row f4) gives the same proof
+    # device-resident witness (HBM hand-off) gives the same proof
     d = ctx.to_device(cs.witness())
     got2 = key.prove(d, mont(opy, 1234567), mont(opy, 7654321))
     _, want = orc.groth16_synthetic_expected(7, n_constraints, n_public, 3, mont(opy, 1234567), mont(opy, 7654321))
@@ -132,7 +132,7 @@ def test_groth16_sharded_by_rows_recombines(ctx, pkg, opy, orc):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# One BSB22 commitment: the statetransition shape (8 public inputs + 1 commitment wire; SURVEY.md rows a10 (1)-(2), a14).
+# One BSB22 commitment: the statetransition shape (8 public inputs + 1 commitment wire).
 # What the reference tree pins is restated in oracle/bn254_py.py (challenge formula, where the commitment enters the
 # verifier's accumulator, the PoK relation): config/statetransition_vkey.sol:393-416,659-700.
 # ---------------------------------------------------------------------------------------------------------------------
@@ -221,7 +221,7 @@ def test_groth16_with_commitment_trapdoor_identity(ctx, pkg, opy, n_constraints,
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# gnark's own key handed over as arrays + proofs from the solver's output (SURVEY.md §8b: the drop-in path for the keys the node
+# gnark's own key handed over as arrays + proofs from the solver's output (the drop-in path for the keys the node
 # loads at circuits/artifacts.go:391-406): export -> import round trip must reproduce the proof bit for bit.
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu

@@ -1,4 +1,4 @@
-"""Groth16 on the voteverifier curve (BLS12-377, SURVEY.md row f1) and on BLS12-381 (prover_gpu.go:45-50): the curve-generic Setup / Prove mirrors
+"""Groth16 on the voteverifier curve (BLS12-377) and on BLS12-381 (prover_gpu.go:45-50): the curve-generic Setup / Prove mirrors
 (csrc/groth16_impl.h) against the closed form a known trapdoor gives (oracle/curves_py.py).  Parity unpinned by the
 reference (no vectors); the trapdoor identity is exact: Ar = [alpha + A(tau) + r delta] G1 etc."""
 from math import isqrt
@@ -105,7 +105,7 @@ def test_groth16_trapdoor_identity_other_curves(ctx, pkg, S, n_constraints, n_pu
 
 @pytest.mark.gpu
 def test_imported_key_on_other_curves(ctx, pkg, S):
-    """The gnark-key path (pk_import + prove_solved, SURVEY.md §8b) on the voteverifier / aggregator / BLS12-381 curves: a key
+    """The gnark-key path (pk_import + prove_solved) on the voteverifier / aggregator / BLS12-381 curves: a key
     exported from the Setup mirror and imported again proves from the solver's (w, a, b, c) to the same proof and to the trapdoor
     identity."""
     from oracle import curves_py as cp

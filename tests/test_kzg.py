@@ -1,4 +1,4 @@
-"""EIP-4844 / EIP-7594 blob KZG (SURVEY.md §8 row f3; /root/reference/types/blobs.go:88-133, crypto/blobs/blob.go:40-90).
+"""EIP-4844 / EIP-7594 blob KZG (/root/reference/types/blobs.go:88-133, crypto/blobs/blob.go:40-90).
 
 Part 1 (CPU): the oracle (oracle/kzg_py.py) PINNED by data the reference itself holds -- the embedded trusted setup
 (two bases of the same tau), the omega table of crypto/blobs/omega.go, the root-of-unity literal of barycentric.go:52 and
@@ -254,7 +254,7 @@ def test_gpu_blob_proof(dev, ts, K, blobs):
 
 @pytest.mark.gpu
 def test_gpu_kzg_concurrent_callers(dev, ctx, pkg, K, ts, blobs, orc):
-    """cgo calls arrive on arbitrary OS threads (SURVEY.md §8b): blob operations, BN254 MSMs and a second setup on the same
+    """cgo calls arrive on arbitrary OS threads: blob operations, BN254 MSMs and a second setup on the same
     context interleave from four threads; every result must still be bit-exact."""
     import threading
     want_c = [dev.compute_commitment(b) for b in blobs]

@@ -1,4 +1,4 @@
-"""Multi-GPU inside the library (SURVEY.md §8e; the node proves one statetransition at a time,
+"""Multi-GPU inside the library (the node proves one statetransition at a time,
 /root/reference/sequencer/statetransition.go:80): dvn_init honours every device ordinal, one proof is spread over the devices
 of a context by entry count, and the partial results are added on the host.  A one-GPU machine rehearses the path with the
 same ordinal listed twice or three times (independent contexts sharing the GPU); results must equal the single-device proof

@@ -48,7 +48,6 @@ def test_generators(opy, orc):
 
 
 def test_montgomery_constants(opy):
-    # SURVEY.md row a15
     assert opy.mont_constants(opy.P)["inv64"] == 0x87D20782E4866389
     assert opy.mont_constants(opy.R)["inv64"] == 0xC2E1F593EFFFFFFF
     assert opy.mont_constants(opy.P)["R_mod"] & 0xFFFFFFF == 0x58F0D9D & 0xFFFFFFF

@@ -1,4 +1,4 @@
-"""Prove -> verify round trips, as the reference's own prover tests are (SURVEY.md §8c), through a restatement of the
+"""Prove -> verify round trips, as the reference's own prover tests are, through a restatement of the
 reference's IN-TREE Solidity verifier (/root/reference/config/statetransition_vkey.sol:393-520,654-744;
 oracle/bn254_pairing_py.py) and of gnark's plain groth16.Verify (circuits/artifacts.go:595-613)."""
 import numpy as np

@@ -1,4 +1,4 @@
-"""The C++ mirror of the reference's `prover` package (SURVEY.md rows a1-a9): UseGPUProver gate, SetProver seam,
+"""The C++ mirror of the reference's `prover` package: UseGPUProver gate, SetProver seam,
 GPU -> CPU fallback with the reference's message, per-curve dispatch.  The 'CPU prover' registered here is a test
 double built on the oracle (in the node it is gnark's groth16.Prove)."""
 import ctypes as C

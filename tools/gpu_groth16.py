@@ -1,4 +1,4 @@
-"""Statetransition-shaped synthetic Groth16: Setup + Prove timings (SURVEY §8d config 5, single GPU)."""
+"""Statetransition-shaped synthetic Groth16: Setup + Prove timings (single GPU)."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,4 +1,4 @@
-"""Blob KZG timings on one MI355X (SURVEY.md row f3): what BlobEvalData.Set costs per state transition
+"""Blob KZG timings on one MI355X: what BlobEvalData.Set costs per state transition
 (/root/reference/crypto/blobs/blob.go:40-90: commitment + 128 cell proofs + proof at z)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,5 +1,5 @@
 """Host-input proving (gnark's solver output in pageable host memory -> proof): dvn_groth16_prove_solved vs the
-device-resident-witness prover on the same key (what PCIe costs per proof, SURVEY.md §8d)."""
+device-resident-witness prover on the same key (what PCIe costs per proof)."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
