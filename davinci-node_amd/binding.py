@@ -182,6 +182,8 @@ def load_library():
         "dvn_prover_set_cpu_backend": (None, [vp, vp]),
         "dvn_prover_last_backend": (i32, []),
         "dvn_prover_prove": (i32, [vp, i32, vp, vp, vp, vp, vp, vp]),
+        "dvn_prover_gpu_prover": (i32, [vp, i32, vp, vp, vp, vp, vp, vp]),
+        "dvn_prover_cpu_prover": (i32, [vp, i32, vp, vp, vp, vp, vp, vp]),
         "dvn_prover_setup": (i32, [vp, vp, u64, C.POINTER(vp)]),
     }
     for name, (res, args) in sig.items():
@@ -214,7 +216,7 @@ EXPORTED_SYMBOLS = [
     "dvn_bw6761_ntt_domain", "dvn_bw6761_ntt", "dvn_bw6761_groth16_compute_h",
     "dvn_bw6761_r1cs_synthetic", "dvn_bw6761_groth16_setup", "dvn_bw6761_groth16_prove",
     "dvn_prover_use_gpu", "dvn_prover_set_use_gpu", "dvn_prover_reload_env", "dvn_prover_set_prover", "dvn_prover_set_cpu_backend",
-    "dvn_prover_last_backend", "dvn_prover_prove", "dvn_prover_setup",
+    "dvn_prover_last_backend", "dvn_prover_prove", "dvn_prover_gpu_prover", "dvn_prover_cpu_prover", "dvn_prover_setup",
     "dvn_ctx_device_count", "dvn_ctx_device", "dvn_ctx_device_ordinal", "dvn_error_string",
     "dvn_msm_g1_share_submit", "dvn_msm_g1_share_collect", "dvn_msm_g1_sum",
     "dvn_groth16_prove_multi", "dvn_groth16_prove_solved_multi", "dvn_bw6761_groth16_prove_solved_multi", "dvn_groth16_last_stats_json",

@@ -74,6 +74,7 @@ int32_t callGPUProver(const Request* q) {
             return fail(DVN_ERR_UNSUPPORTED, "GPU proving not supported for curve %s", curve_name(q->curve));
     }
 }
+void note_backend(int b) { last_backend = b; }
 int32_t GPUProverWithWitness(const Request* q) { last_backend = 1; return callGPUProver(q); }
 // frontend.NewWitness(assignment, field) has no counterpart here: the assignment already is the wire vector
 int32_t CPUProver(const Request* q) { return CPUProverWithWitness(q); }
@@ -127,5 +128,18 @@ extern "C" int32_t dvn_prover_prove(dvn_ctx* ctx, int32_t curve, const dvn_r1cs*
                                     const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out) {
     prover::Request q{curve, ctx, ccs, pk, witness, r_mont, s_mont, proof_out};
     return prover::Prove(&q);
+}
+extern "C" int32_t dvn_prover_gpu_prover(dvn_ctx* ctx, int32_t curve, const dvn_r1cs* ccs, dvn_groth16_pk* pk, const uint64_t* witness,
+                                         const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out) {
+    // a process that holds no device context is this library's "CPU build": the reference's exported stubs there panic with this
+    // text whatever their arguments (prover/prover_cpu.go:41-44, 61-64; pinned by prover/prover_cpu_test.go:7-25)
+    if (!ctx) { prover::note_backend(1); return fail(DVN_ERR_UNSUPPORTED, "GPU prover not supported in this build"); }
+    prover::Request q{curve, ctx, ccs, pk, witness, r_mont, s_mont, proof_out};
+    return prover::GPUProver(&q);
+}
+extern "C" int32_t dvn_prover_cpu_prover(dvn_ctx* ctx, int32_t curve, const dvn_r1cs* ccs, dvn_groth16_pk* pk, const uint64_t* witness,
+                                         const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out) {
+    prover::Request q{curve, ctx, ccs, pk, witness, r_mont, s_mont, proof_out};
+    return prover::CPUProver(&q);
 }
 extern "C" int32_t dvn_prover_setup(dvn_ctx* ctx, const dvn_r1cs* ccs, uint64_t seed, dvn_groth16_pk** pk) { return prover::Setup(ctx, ccs, seed, pk); }

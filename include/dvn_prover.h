@@ -251,6 +251,14 @@ void dvn_prover_set_cpu_backend(dvn_cpu_backend b, void* user);
 int32_t dvn_prover_last_backend(void);                              /* 1 GPU, 2 CPU backend, 3 custom prover func */
 int32_t dvn_prover_prove(dvn_ctx* ctx, int32_t curve, const dvn_r1cs* ccs, dvn_groth16_pk* pk, const uint64_t* witness,
                          const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out);
+/* The two provers behind the seam, callable directly as the reference's exported GPUProver / CPUProver are
+ * (/root/reference/prover/prover_gpu.go:87-106).  Without a device context (ctx == NULL: what a host without a GPU has after
+ * dvn_init failed) dvn_prover_gpu_prover fails with "GPU prover not supported in this build", the text the reference's
+ * CPU-build stubs panic with (/root/reference/prover/prover_cpu.go:41-44,61-64; prover_cpu_test.go:7-25). */
+int32_t dvn_prover_gpu_prover(dvn_ctx* ctx, int32_t curve, const dvn_r1cs* ccs, dvn_groth16_pk* pk, const uint64_t* witness,
+                              const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out);
+int32_t dvn_prover_cpu_prover(dvn_ctx* ctx, int32_t curve, const dvn_r1cs* ccs, dvn_groth16_pk* pk, const uint64_t* witness,
+                              const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out);
 int32_t dvn_prover_setup(dvn_ctx* ctx, const dvn_r1cs* ccs, uint64_t seed, dvn_groth16_pk** pk);   /* prover.Setup */
 
 /* ---- BLS12-377 ------------------------------------------------------------------------------------ */

@@ -45,6 +45,23 @@ def test_cpu_path_without_backend_errors_loudly(L, pkg):
     cs.free()
 
 
+def test_gpu_prover_without_a_device_context_is_refused(L, pkg):
+    """prover/prover_cpu_test.go:7-25: in a build without GPU support GPUProver and GPUProverWithWitness panic with
+    "GPU prover not supported in this build".  This library's counterpart of that build is a process without a device
+    context; C has no panic, the call fails with the same text -- also through Prove when GPU_PROVER is on and no CPU
+    backend is registered (the fallback then fails loudly too)."""
+    cs = pkg.R1CS(11, 13, 3)
+    out = np.zeros(32, dtype=np.uint64); r = np.zeros(4, dtype=np.uint64)
+    w = cs.witness()
+    rc = L.dvn_prover_gpu_prover(None, 1, cs.h, None, w.ctypes.data, r.ctypes.data, r.ctypes.data, out.ctypes.data)
+    assert rc == -5 and L.dvn_last_error(None) == b"GPU prover not supported in this build"
+    assert L.dvn_prover_last_backend() == 1
+    assert L.dvn_prover_gpu_prover(None, 0, None, None, None, None, None, None) == -5        # GPUProver(0, nil, nil, nil)
+    rc = L.dvn_prover_cpu_prover(None, 1, cs.h, None, w.ctypes.data, r.ctypes.data, r.ctypes.data, out.ctypes.data)
+    assert rc == -5 and b"CPU prover not linked" in L.dvn_last_error(None)
+    cs.free()
+
+
 def _oracle_backend(orc, seeds, calls):
     from davinci_node_amd import binding
     L_ = binding.load_library()
