@@ -76,22 +76,32 @@ template <class F> struct Curve {
     // normalised -- so the additive steps are single carry passes and Y3 shares one Montgomery reduction between its
     // two products.  Bounds (units of p): P = U2 + 8p - X1 < 9.1, R = S2 + 2p - Y1 < 3.1, PP < 1.5, PPP, Q, RR < 1.1,
     // X3 = RR + 2p - PPP + 4p - 2Q < 7.1, QX = Q + 8p - X3 < 9.1, Y3 = (R QX + (2p - Y1) PPP)/R' < 1.2.
-    static DVN_HD X acc_add_mixed(const X& p, const A& q) {
+    static DVN_HD X acc_add_mixed(const X& p, const A& q) { return acc_add_mixed_signed(p, q, false); }
+    // p + q, or p - q when `negate`: the sign of a sorted MSM entry is folded into the one subtraction that reads q.y
+    // (R = +-S2 - Y1) instead of negating the point first
+    static DVN_HD X acc_add_mixed_signed(const X& p, const A& q, bool negate) {
         if constexpr (!O::LAZY) {
-            return add_mixed(p, q);
+            return add_mixed(p, negate ? neg(q) : q);
         } else {
             typedef typename O::Cfg C;
             if (is_inf(q)) return p;
-            if (is_inf(p)) return X{q.x, q.y, O::one(), O::one()};
+            if (is_inf(p)) return X{q.x, negate ? O::neg(q.y) : q.y, O::one(), O::one()};
             const F U2 = O::mul(q.x, p.zz), S2 = O::mul(q.y, p.zzz);
-            const F P = fe_sub_lazy<C, 8>(U2, p.x), R = fe_sub_lazy<C, 2>(S2, p.y);
+            const F P = fe_sub_lazy<C, 8>(U2, p.x), R = fe_sub_lazy_cneg<C>(S2, p.y, negate);
             if (fe_is_zero_loose<C>(P)) {
-                if (fe_is_zero_loose<C>(R)) return dbl_affine(q);
+                if (fe_is_zero_loose<C>(R)) return dbl_affine(negate ? neg(q) : q);
                 return infinity();
             }
             const F PP = O::sqr(P), PPP = O::mul(P, PP), Q = O::mul(p.x, PP);
-            const F X3 = fe_sub_lazy<C, 4>(fe_sub_lazy<C, 2>(O::sqr(R), PPP), fe_add_nocarry<C>(Q, Q));
-            const F Y3 = fe_mul_add<C>(R, fe_sub_lazy<C, 8>(Q, X3), fe_neg_lazy<C, 2>(p.y), PPP);
+            // products are below 1.7p here (P < 10p, R < 4p, X1 < 8p): PPP + 2Q < 6p, X3 < R^2 + 6p < 8p
+            const F X3 = fe_sub2_lazy6<C>(O::sqr(R), PPP, Q);
+            F D;                                                  // Q - X3 + K p, the second operand of R in Y3
+            if constexpr (fe_mul_add_raw_fits<C>()) D = fe_sub_raw<C, 16, LB>(Q, X3);     // raw limbs: no carry pass
+            else D = fe_sub_lazy<C, 8>(Q, X3);
+            F NY;                                                 // K p - Y1 (Y1 < 2p), the first operand of PPP in Y3
+            if constexpr (fe_mul_add_raw2_fits<C>()) NY = fe_neg_raw<C, 4, LB>(p.y);
+            else NY = fe_neg_lazy<C, 2>(p.y);
+            const F Y3 = fe_mul_add<C>(D, R, NY, PPP);
             return X{X3, Y3, O::mul(p.zz, PP), O::mul(p.zzz, PPP)};
         }
     }

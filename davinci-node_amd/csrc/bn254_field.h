@@ -201,6 +201,32 @@ template <class C, int K> DVN_HD Fe<C> fe_csub(const Fe<C>& x) {
     for (int i = 0; i < C::NL; ++i) r.v[i] = neg ? x.v[i] : (u32)d[i];
     return r;
 }
+// neg ? (4p - s - y) : (s + 2p - y)  for s, y < 2p: the lazily reduced difference of fe_sub_lazy<2> with the sign of s folded in
+// (one carry pass; no separate negation of s).  Value below 4p either way.
+template <class C> DVN_HD Fe<C> fe_sub_lazy_cneg(const Fe<C>& s, const Fe<C>& y, bool neg) {
+    i32 d[C::NL];
+#pragma unroll
+    for (int i = 0; i < C::NL; ++i) {
+        const i32 pos = (i32)s.v[i] + (i32)C::p2(i), ng = (i32)C::p4(i) - (i32)s.v[i];
+        d[i] = (neg ? ng : pos) - (i32)y.v[i];
+    }
+    fe_carry<C>(d);
+    Fe<C> r;
+#pragma unroll
+    for (int i = 0; i < C::NL; ++i) r.v[i] = (u32)d[i];
+    return r;
+}
+// a + 6p - b - 2c with one carry pass (requires b + 2c <= 6p): value below a + 6p
+template <class C> DVN_HD Fe<C> fe_sub2_lazy6(const Fe<C>& a, const Fe<C>& b, const Fe<C>& c) {
+    i32 d[C::NL];
+#pragma unroll
+    for (int i = 0; i < C::NL; ++i) d[i] = (i32)a.v[i] + (i32)(C::p2(i) + C::p4(i)) - (i32)b.v[i] - (i32)(c.v[i] << 1);
+    fe_carry<C>(d);
+    Fe<C> r;
+#pragma unroll
+    for (int i = 0; i < C::NL; ++i) r.v[i] = (u32)d[i];
+    return r;
+}
 // a + b without carry propagation: limbs < 2^30; only valid as the subtrahend of fe_sub_lazy or a fe_mul operand
 template <class C> DVN_HD Fe<C> fe_add_nocarry(const Fe<C>& a, const Fe<C>& b) {
     Fe<C> r;
@@ -239,6 +265,27 @@ template <class C, int K, int SH> DVN_HD Fe<C> fe_sub_raw(const Fe<C>& a, const 
 template <class C> DVN_HD constexpr bool fe_mul_raw_fits(u64 max_limb) {
     const unsigned __int128 cols = (unsigned __int128)C::NL * max_limb * LMASK + (unsigned __int128)C::NL * LMASK * LMASK + ((unsigned __int128)1 << 36);
     return (cols >> 64) == 0;
+}
+// fe_mul_add(a, b, c, d) with a raw a (limbs below 3 * 2^29, as fe_sub_raw<.., .., 29> of normalised values gives) and b, c, d
+// normalised: NL raw products + NL normalised products + the reduction's NL products per column
+template <class C> DVN_HD constexpr bool fe_mul_add_raw_fits() {
+    const unsigned __int128 cols = (unsigned __int128)C::NL * (3ull << LB) * LMASK + 2 * (unsigned __int128)C::NL * LMASK * LMASK + ((unsigned __int128)1 << 36);
+    return (cols >> 64) == 0;
+}
+// ... and with c raw as well (limbs below 2 * 2^29, as fe_neg_raw gives)
+template <class C> DVN_HD constexpr bool fe_mul_add_raw2_fits() {
+    const unsigned __int128 cols = (unsigned __int128)C::NL * (5ull << LB) * LMASK + (unsigned __int128)C::NL * LMASK * LMASK + ((unsigned __int128)1 << 36);
+    return (cols >> 64) == 0;
+}
+// K p - b with no carry pass (the offset pattern of fe_sub_raw): limbs below 2^SH + 2^29
+template <class C, int K, int SH> DVN_HD Fe<C> fe_neg_raw(const Fe<C>& b) {
+    Fe<C> r;
+#pragma unroll
+    for (int i = 0; i < C::NL; ++i) {
+        const u32 k = fe_kp_limb<C, K>(i) + (i < C::NL - 1 ? (1u << SH) : 0u) - (i > 0 ? (1u << (SH - LB)) : 0u);
+        r.v[i] = k - b.v[i];
+    }
+    return r;
 }
 // one unsigned carry pass: limbs < 2^32 in, limbs 0..NL-2 normalised out
 template <class C> DVN_HD Fe<C> fe_normalise(const Fe<C>& a) {

@@ -78,8 +78,7 @@ void hc_g1_acc_chain(const uint32_t* pts, const uint32_t* idx, size_t n, uint32_
     G1::X acc = G1::infinity();
     for (size_t i = 0; i < n; ++i) {
         G1::A p = G1::affine_from_ext(pts + 16 * (size_t)(idx[i] & 0x7fffffffu));
-        if (idx[i] & 0x80000000u) p = G1::neg(p);
-        acc = G1::acc_add_mixed(acc, p);
+        acc = G1::acc_add_mixed_signed(acc, p, (idx[i] & 0x80000000u) != 0);     // as k_accumulate does
     }
     G1::affine_to_ext(G1::to_affine(G1::acc_normalize(acc)), out);
 }
@@ -130,8 +129,7 @@ void hc377_g1_acc_chain(const uint32_t* pts, const uint32_t* idx, size_t n, uint
     G1_377::X acc = G1_377::infinity();
     for (size_t i = 0; i < n; ++i) {
         G1_377::A p = G1_377::affine_from_ext(pts + (size_t)G1_377::AW * (idx[i] & 0x7fffffffu));
-        if (idx[i] & 0x80000000u) p = G1_377::neg(p);
-        acc = G1_377::acc_add_mixed(acc, p);
+        acc = G1_377::acc_add_mixed_signed(acc, p, (idx[i] & 0x80000000u) != 0);     // as k_accumulate does
     }
     G1_377::affine_to_ext(G1_377::to_affine(G1_377::acc_normalize(acc)), out);
 }
@@ -152,8 +150,7 @@ void hc381_g1_acc_chain(const uint32_t* pts, const uint32_t* idx, size_t n, uint
     G1_381::X acc = G1_381::infinity();
     for (size_t i = 0; i < n; ++i) {
         G1_381::A p = G1_381::affine_from_ext(pts + (size_t)G1_381::AW * (idx[i] & 0x7fffffffu));
-        if (idx[i] & 0x80000000u) p = G1_381::neg(p);
-        acc = G1_381::acc_add_mixed(acc, p);
+        acc = G1_381::acc_add_mixed_signed(acc, p, (idx[i] & 0x80000000u) != 0);     // as k_accumulate does
     }
     G1_381::affine_to_ext(G1_381::to_affine(G1_381::acc_normalize(acc)), out);
 }
@@ -185,8 +182,7 @@ void hc761_acc_chain(const uint32_t* pts, const uint32_t* idx, size_t n, uint32_
     G_761::X acc = G_761::infinity();
     for (size_t i = 0; i < n; ++i) {
         G_761::A p = G_761::affine_from_ext(pts + (size_t)G_761::AW * (idx[i] & 0x7fffffffu));
-        if (idx[i] & 0x80000000u) p = G_761::neg(p);
-        acc = G_761::acc_add_mixed(acc, p);
+        acc = G_761::acc_add_mixed_signed(acc, p, (idx[i] & 0x80000000u) != 0);     // as k_accumulate does
     }
     G_761::affine_to_ext(G_761::to_affine(G_761::acc_normalize(acc)), out);
 }

@@ -568,8 +568,7 @@ __global__ __launch_bounds__(128, AccMinBlocks<Cv>::value) void k_accumulate(con
         }
         const u32 e = src[x];
         A p = ld_affine<Cv>(points + (pts_off + (size_t)(e & ~SIGN_BIT)) * Cv::AW);
-        if (e & SIGN_BIT) p = Cv::neg(p);
-        acc = Cv::acc_add_mixed(acc, p);
+        acc = Cv::acc_add_mixed_signed(acc, p, (e & SIGN_BIT) != 0);
     }
 #elif DVN_ACC_PREFETCH == 1
     // the sorted entry of iteration x + 1 is fetched before the addition of iteration x: the point gather of the next iteration
@@ -584,8 +583,7 @@ __global__ __launch_bounds__(128, AccMinBlocks<Cv>::value) void k_accumulate(con
         }
         const u32 e_next = src[x + 1 < pos1 ? x + 1 : x];
         A p = ld_affine<Cv>(points + (pts_off + (size_t)(e & ~SIGN_BIT)) * Cv::AW);
-        if (e & SIGN_BIT) p = Cv::neg(p);
-        acc = Cv::acc_add_mixed(acc, p);
+        acc = Cv::acc_add_mixed_signed(acc, p, (e & SIGN_BIT) != 0);
         e = e_next;
     }
 #else

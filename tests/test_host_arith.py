@@ -181,3 +181,25 @@ def test_carry_free_butterfly_forms(hc, field):
         w = norm(mod - 1 - rng.randrange(1 << 50) if it % 2 else rng.randrange(mod))
         got = call(5, a, w)
         assert all(v < B for v in got[:-1]) and val(got) < 2 * mod and val(got) % mod == val(a) * val(w) * Rinv % mod, it
+
+
+def test_lazy_accumulator_chain_with_signs(hc, opy, orc):
+    """k_accumulate's loop body on the host: the lazily reduced XYZZ accumulator with the entry's sign folded into the
+    addition (acc_add_mixed_signed), against the oracle's affine group law -- plain sums, P + P (doubling branch), P - P
+    (infinity, then restart), a negated first entry, -P - P, and long random chains that keep the accumulator loose."""
+    import random
+    o = opy
+    pts = orc.g1_synthetic_points(21, 16)
+    aff = [o.g1_from_limbs([int(v) for v in r]) for r in pts]
+    rng = random.Random(7)
+    N = 1 << 31
+    cases = [[0, 1, 2, 3], [5, 5], [5, 5 | N], [5, 5 | N, 7], [5 | N], [5 | N, 5 | N], [5 | N, 5], [3] * 20, [3 | N] * 9 + [3] * 9 + [4 | N]]
+    cases += [[rng.randrange(16) | (N if rng.random() < 0.5 else 0) for _ in range(rng.randrange(2, 200))] for _ in range(40)]
+    for idx in cases:
+        ia = np.array(idx, dtype=np.uint32); r = np.zeros(8, dtype=np.uint64)
+        hc.hc_g1_acc_chain(p(pts), p(ia), C.c_size_t(len(idx)), p(r))
+        acc = None
+        for e in idx:
+            pt = aff[e & 0x7fffffff]
+            acc = o.g1_add(acc, o.g1_neg(pt) if e >> 31 else pt)
+        assert [int(v) for v in r] == o.g1_to_limbs(acc), idx[:8]

@@ -4,7 +4,8 @@ d = json.load(open(sys.argv[1]))
 print("value", d["value"], d["unit"], "ms_per_step", d["ms_per_step"])
 r = d["roofline"]
 print("kernel_ms", r["kernel_ms"], "frac", r["frac"], "int frac", r.get("int_issue_context", {}).get("frac"))
-print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["unit"], d["cpu_baseline"]["cores"])
+cb = d.get("cpu_baseline") or {}
+print("cpu", cb.get("value"), cb.get("unit"), cb.get("cores"))
 for k, v in d["config"].items():
     print("config", k, v)
 for k, v in d.get("extras", {}).items():
