@@ -467,7 +467,18 @@ extern "C" int32_t dvn_groth16_pk_load_file(dvn_ctx* ctx, const char* path, cons
         if (hit) *out = hit;
         else {
             rc = load_image(ctx, (const uint8_t*)map, len, n_public, committed_wires, n_committed_wires, out);
-            if (rc == DVN_OK) { (*out)->cached = true; std::lock_guard<std::mutex> lk(ctx->mu); ctx->key_cache.emplace_back(hex, *out); }
+            if (rc == DVN_OK) {
+                // two threads may have loaded the same file at once: the first to get here owns the cache entry, the other
+                // hands back the resident key and drops its own copy
+                dvn_groth16_pk* loser = nullptr;
+                {
+                    std::lock_guard<std::mutex> lk(ctx->mu);
+                    for (auto& kv : ctx->key_cache) if (kv.first == hex) hit = kv.second;
+                    if (hit) { loser = *out; *out = hit; }
+                    else { (*out)->cached = true; ctx->key_cache.emplace_back(hex, *out); }
+                }
+                if (loser) (void)dvn_groth16_pk_free(ctx, loser);
+            }
         }
     }
     munmap(map, len);

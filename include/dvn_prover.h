@@ -419,7 +419,10 @@ int32_t dvn_bw6761_groth16_pk_export_arrays(dvn_ctx* ctx, const dvn_groth16_pk* 
  * (BN254; compressed or raw point encodings) straight into a device-resident key for dvn_groth16_prove_solved: the points
  * are decompressed on the device, the InfinityA / InfinityB bitmaps become the wire lists of A and B, and K's wire list is
  * [n_public, nbWires) minus committed_wires -- the two facts the key file does not carry come from the constraint system
- * gnark loads beside it (ccs.GetNbPublicVariables(), the PrivateCommitted indices of its one commitment).  sha256_hex: the
+ * gnark loads beside it: ccs.GetNbPublicVariables(), and for committed_wires every private wire whose K point gnark's Setup
+ * leaves out of pk.G1.K, i.e. the PrivateCommitted indices of the commitment TOGETHER WITH its CommitmentIndex wire (the wire
+ * that receives the challenge: Setup moves its K point into the verifying key).  The count is checked against |G1.K|.
+ * A cache hit returns the resident key without looking at n_public / committed_wires again.  sha256_hex: the
  * expected content hash (the file's name in the node's cache) or NULL; a mismatch is DVN_ERR_INVALID_ARG.  Keys are cached per
  * context by content hash: loading the same file again returns the resident key, and cached keys live until dvn_shutdown
  * (dvn_groth16_pk_free leaves them alone).  _load_bytes: the same reader on a memory image, uncached.  dvn_gnark_pk_scan

@@ -171,3 +171,60 @@ def test_malformed_points_are_rejected(ctx, pkg, opy):
         pkg.LoadedKey(ctx, bytes(mixed), 2)
     ok = pkg.LoadedKey(ctx, bytes(img), 2)
     ok.free()
+
+
+def test_scan_survives_mutated_images(pkg, opy):
+    """A key file is input from disk: the host-side section walk must reject damaged images with an error, never read out of
+    bounds.  Truncations at every section border +-1, single-byte and 32-bit-count mutations, random tails."""
+    import random
+    from oracle import gnark_key_format_py as fmt
+    rng = random.Random(11)
+    for raw in (False, True):
+        img = _tiny_image(opy, fmt, raw, True, commitment=True)
+        good = pkg.gnark_pk_scan(img)
+        n_ok = n_err = 0
+        cuts = sorted(set(list(range(0, len(img), 37)) + [len(img) - k for k in range(1, 70)]))
+        variants = [img[:c] for c in cuts]
+        for _ in range(600):
+            b = bytearray(img)
+            k = rng.randrange(4)
+            if k == 0:
+                b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+            elif k == 1:
+                off = rng.randrange(len(b) - 4); b[off:off + 4] = rng.getrandbits(32).to_bytes(4, "big")
+            elif k == 2:
+                off = rng.randrange(len(b) - 8); b[off:off + 8] = (rng.getrandbits(rng.choice((8, 20, 40, 63)))).to_bytes(8, "big")
+            else:
+                b += bytes(rng.getrandbits(8) for _ in range(rng.randrange(1, 40)))
+            variants.append(bytes(b))
+        for v in variants:
+            try:
+                info = pkg.gnark_pk_scan(v)
+                n_ok += 1
+                assert info["n_wires"] == good["n_wires"] and info["A"] <= good["n_wires"]        # a mutation inside point bytes
+            except pkg.DvnError:
+                n_err += 1
+        assert n_err > 100 and n_ok > 0, (n_ok, n_err)
+
+
+@pytest.mark.gpu
+def test_concurrent_loads_of_one_file_share_one_key(ctx, pkg, opy, tmp_path):
+    """cgo calls arrive on arbitrary threads: several goroutines asking for the same artifact at once end up with ONE resident
+    key (the losers of the race drop their copy)."""
+    import threading
+    from oracle import gnark_key_format_py as fmt
+    img = _tiny_image(opy, fmt, raw=False)
+    digest = hashlib.sha256(img).hexdigest()
+    path = tmp_path / digest
+    path.write_bytes(img)
+    got, errs = [], []
+
+    def load():
+        try:
+            got.append(pkg.LoadedKey(ctx, path, 2, sha256_hex=digest).h.value)
+        except Exception as e:                                     # noqa: BLE001 - reported below
+            errs.append(e)
+    th = [threading.Thread(target=load) for _ in range(6)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errs and len(got) == 6 and len(set(got)) == 1
