@@ -8,5 +8,5 @@ cb = d.get("cpu_baseline") or {}
 print("cpu", cb.get("value"), cb.get("unit"), cb.get("cores"))
 for k, v in d["config"].items():
     print("config", k, v)
-for k, v in d.get("extras", {}).items():
+for k, v in (d.get("extras") or {}).items():
     print("extra", k, json.dumps(v)[:260])
