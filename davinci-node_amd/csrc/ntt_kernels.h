@@ -7,7 +7,7 @@
 //
 // One launch = one PASS of up to 8 consecutive radix-2 stages on LDS-resident tiles: a tile is I (<= 8)
 // neighbouring sub-problems of 2^K elements, so every global access is a run of I * 32 B = 256 B and the
-// 2^K * I * 32 B tile (<= 64 KiB) sees K stages for one HBM read + one HBM write.  Twiddles come from
+// 2^K * I-element tile (2048 elements of nine limbs = 72 KiB of LDS) sees K stages for one HBM read + one HBM write.  Twiddles come from
 // per-stage tables table_s[k] = w^(k * 2^s) in HBM (contiguous in k, i.e. coalesced across a tile row); the
 // late, small tables stay in L2 / Infinity Cache.
 //
