@@ -32,7 +32,8 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 BYTES_PER_PAIR = 96            # 32 B scalar + 64 B affine point
 # secondary (integer-issue) roofline of the dominant kernel -- context only, the contract's roofline is the HBM one:
 MADS_PER_ADD = 1467            # v_mad_u64_u32 per XYZZ mixed addition in k_accumulate's loop body (counted in the ISA)
-MAD_PEAK_PER_S = 35.4e12       # chip-wide v_mad_u64_u32 lane-op/s measured by tools/microbench (profiles/r01_instr_rate_microbench.txt)
+MAD_PEAK_PER_S = 35.4e12       # chip-wide v_mad_u64_u32 lane-op/s: the highest rate tools/microbench measured (profiles/r01_instr_rate_microbench.txt;
+                               # tools/microbench/valu_rates.hip on other boxes: 28.7-30.5e12)
 
 
 def pmc_traffic(log_n, world):

@@ -1,6 +1,6 @@
 // Issue cost of the instructions a wide-integer multiplication can be built from, in cycles per wave64 instruction per
 // SIMD with every SIMD saturated: v_mad_u64_u32, v_fma_f64, v_add_f64, v_lshl_add_u64, v_mul_lo_u32, v_mul_hi_u32,
-// v_mad_u32_u24, v_add_u32.  Each kernel runs ITER rounds of 8 independent chains of one operation.
+// v_mad_u32_u24, v_add3_u32 (VOP3 encodings) and v_add_u32, v_and_b32, v_lshrrev_b32 (VOP2 encodings).  Each kernel runs ITER rounds of 8 independent chains of one operation.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -30,6 +30,10 @@ template <int OP> __global__ __launch_bounds__(256) void k(u64* out, u32 seed, i
             if (OP == 8) asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(w[i]) : "v"(m));
             if (OP == 9) asm volatile("v_lshrrev_b64 %0, 29, %0" : "+v"(a[i]));
             if (OP == 10) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[i]) : "v"(fm));
+            if (OP == 11) asm volatile("v_add_u32_e32 %0, %0, %1" : "+v"(w[i]) : "v"(m));           // VOP2 encodings
+            if (OP == 12) asm volatile("v_and_b32_e32 %0, %1, %0" : "+v"(w[i]) : "v"(m));
+            if (OP == 13) asm volatile("v_lshrrev_b32_e32 %0, 3, %0" : "+v"(w[i]));
+            if (OP == 15) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(w[i]) : "v"(m));
         }
     }
     u64 r = 0;
@@ -61,5 +65,7 @@ int main() {
     run<0>("mad_u64_u32", out, cus, mhz); run<1>("fma_f64", out, cus, mhz); run<2>("add_f64", out, cus, mhz); run<3>("lshl_add_u64", out, cus, mhz);
     run<4>("mul_lo_u32", out, cus, mhz); run<5>("mul_hi_u32", out, cus, mhz); run<6>("mad_u32_u24", out, cus, mhz); run<7>("add3_u32", out, cus, mhz);
     run<8>("mul_hi_u32_u24", out, cus, mhz); run<9>("lshrrev_b64", out, cus, mhz); run<10>("mul_f64", out, cus, mhz);
+    run<11>("add_u32 (VOP2)", out, cus, mhz); run<12>("and_b32 (VOP2)", out, cus, mhz); run<13>("lshrrev_b32 (VOP2)", out, cus, mhz);
+    run<15>("fma_f32", out, cus, mhz); run<0>("mad_u64_u32 again", out, cus, mhz);
     hipFree(out); return 0;
 }
