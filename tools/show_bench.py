@@ -1,6 +1,6 @@
 """Print the headline fields of a bench.py JSON line (file argument), one per row."""
 import json, sys
-d = json.load(open(sys.argv[1]))
+d = [json.loads(l) for l in open(sys.argv[1]) if l.lstrip().startswith("{")][-1]
 print("value", d["value"], d["unit"], "ms_per_step", d["ms_per_step"])
 r = d["roofline"]
 print("kernel_ms", r["kernel_ms"], "frac", r["frac"], "int frac", r.get("int_issue_context", {}).get("frac"))
