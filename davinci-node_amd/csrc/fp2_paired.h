@@ -45,12 +45,15 @@ template <class C> struct Ops<Fe2P<C>> {
         if constexpr (BETA == 1) return x;
         else { const Fe<C> x2 = fe_add_lazy<C>(x, x), x4 = fe_add_lazy<C>(x2, x2); return fe_add_lazy<C>(x4, x); }   // BETA = 5
     }
-    // even lane: a0 b0 + (2p - a1)(BETA b1);  odd lane: a0 b1 + a1 b0   (mine = own component, part = partner's)
+    // even lane: a0 b0 + (4p - a1)(BETA b1);  odd lane: a0 b1 + a1 b0   (mine = own component, part = partner's)
     static __device__ __forceinline__ F mul(const F& a, const F& b) {
         const bool odd = pair_odd();
         const Fe<C> pa = fe_partner<C>(a.c), pb = fe_partner<C>(b.c);
         const Fe<C> U = fe_select<C>(odd, pa, a.c);                                  // a0
-        const Fe<C> S = fe_select<C>(odd, a.c, fe_neg_lazy<C, 2>(pa));              // a1 | 2p - a1
+        // a1 | 4p - a1 with no carry pass: as the first operand of the second product its limbs may reach 2^30 (the columns of
+        // fe_mul_add hold NL * (1 + 2 + 1) * 2^58 < 2^64 for NL <= 16)
+        static_assert(C::NL <= 16, "column headroom of the raw operand");
+        const Fe<C> S = fe_select<C>(odd, a.c, fe_neg_raw<C, 4, LB>(pa));
         const Fe<C> T = fe_select<C>(odd, pb, mul_beta_lazy(pb));                    // b0 | BETA b1
         return F{fe_mul_add<C>(U, b.c, S, T)};                                       // V = own b component
     }
