@@ -891,7 +891,9 @@ template <class SU> static int32_t groth16_prove_multi(dvn_ctx* ctx, dvn_groth16
     std::vector<int32_t> rcs(ndev, DVN_OK);
     std::vector<std::string> errs(ndev);
     std::vector<std::thread> threads;
-    for (uint32_t i = 0; i < ndev; ++i) {
+    bool spawn_failed = false;
+    for (uint32_t i = 0; i < ndev && !spawn_failed; ++i) {
+        try {
         threads.emplace_back([&, i]() {
             dvn_ctx* ci = i == 0 ? ctx : ctx->peers[i - 1];
             int32_t rc = enter(ci);                             // hipSetDevice on this thread
@@ -903,8 +905,10 @@ template <class SU> static int32_t groth16_prove_multi(dvn_ctx* ctx, dvn_groth16
             rcs[i] = rc;
             if (rc != DVN_OK) errs[i] = tl_error;
         });
+        } catch (...) { spawn_failed = true; }                  // no exception may cross the C boundary
     }
     for (auto& t : threads) t.join();
+    if (spawn_failed) return fail(DVN_ERR_OOM, "could not start a host thread per device");
     for (uint32_t i = 0; i < ndev; ++i)
         if (rcs[i] != DVN_OK) return fail(rcs[i], "device share %u of %u failed: %s", i, ndev, errs[i].c_str());
     RoctxRange rr("dvn:host_combine");
