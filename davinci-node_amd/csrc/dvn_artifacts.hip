@@ -427,7 +427,9 @@ int32_t dvn_internal_key_cache_clear(dvn_ctx* ctx) {
 extern "C" int32_t dvn_gnark_pk_scan(const uint8_t* data, size_t len, uint64_t info[11]) {
     if (!data || !info) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     Layout L; std::string why;
-    if (!scan_any(data, len, &L, &why)) return fail(DVN_ERR_INVALID_ARG, "not a gnark BN254 proving key: %s", why.c_str());
+    try {
+        if (!scan_any(data, len, &L, &why)) return fail(DVN_ERR_INVALID_ARG, "not a gnark BN254 proving key: %s", why.c_str());
+    } catch (...) { return fail(DVN_ERR_OOM, "host allocation failed while reading the key"); }      // nothing is thrown across the C boundary
     info[0] = L.log_n; info[1] = L.raw; info[2] = L.n_wires; info[3] = L.A.count; info[4] = L.B.count; info[5] = L.Z.count; info[6] = L.K.count;
     info[7] = L.B2.count; info[8] = L.n_commitments; info[9] = L.n_commitments ? L.basis[0].count : 0; info[10] = L.precompute_flag;
     return DVN_OK;
@@ -436,7 +438,8 @@ extern "C" int32_t dvn_groth16_pk_load_bytes(dvn_ctx* ctx, const uint8_t* data, 
                                              uint32_t n_committed_wires, dvn_groth16_pk** out) {
     TRY(enter(ctx));
     if (!data || !out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
-    return load_image(ctx, data, len, n_public, committed_wires, n_committed_wires, out);
+    try { return load_image(ctx, data, len, n_public, committed_wires, n_committed_wires, out); }
+    catch (...) { return fail(DVN_ERR_OOM, "host allocation failed while reading the key"); }
 }
 // path: the artifact file; sha256_hex: its expected content hash (the file's name in the node's cache) or NULL to skip the
 // check.  A key with the same hash already resident on this context is returned as is (one upload per process).
@@ -466,7 +469,8 @@ extern "C" int32_t dvn_groth16_pk_load_file(dvn_ctx* ctx, const char* path, cons
         { std::lock_guard<std::mutex> lk(ctx->mu); for (auto& kv : ctx->key_cache) if (kv.first == hex) hit = kv.second; }
         if (hit) *out = hit;
         else {
-            rc = load_image(ctx, (const uint8_t*)map, len, n_public, committed_wires, n_committed_wires, out);
+            try { rc = load_image(ctx, (const uint8_t*)map, len, n_public, committed_wires, n_committed_wires, out); }
+            catch (...) { rc = fail(DVN_ERR_OOM, "host allocation failed while reading the key"); }
             if (rc == DVN_OK) {
                 // two threads may have loaded the same file at once: the first to get here owns the cache entry, the other
                 // hands back the resident key and drops its own copy
