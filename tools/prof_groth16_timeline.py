@@ -8,11 +8,10 @@ for r in rows:
     n = re.sub(r"<.*Fe2P.*", "<G2>", n); n = re.sub(r"<.*", "", n) if "<G2>" not in n else n
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n, r["Queue_Id"]))
 ev.sort()
-# the last proof = everything after the last k_r1cs / solve kernel start; fall back to the last 150 kernels
-starts = [i for i, e in enumerate(ev) if e[2].startswith("k_r1cs") or e[2].startswith("k_spmv") or e[2].startswith("k_solve")]
-i0 = starts[-1] if starts else max(0, len(ev) - 150)
-# walk back to the first kernel of that proof (gap > 1 ms before it)
-while i0 > 0 and ev[i0][0] - ev[i0 - 1][1] < 300000: i0 -= 1
+# a proof starts with the wire filter (two k_gather_fr launches on the main stream); the last proof = everything from the last such
+# pair on, minus a small lead for the witness copy
+starts = [i for i, e in enumerate(ev) if e[2].startswith("k_gather_fr")]
+i0 = starts[-2] if len(starts) >= 2 else max(0, len(ev) - 150)
 t0 = ev[i0][0]; t1 = max(e[1] for e in ev[i0:])
 print(f"proof span {(t1 - t0) / 1e6:.3f} ms, {len(ev) - i0} kernels")
 def union(iv):
