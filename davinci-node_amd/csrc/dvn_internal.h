@@ -34,6 +34,7 @@ struct MsmLane {
     u32* h_sums = nullptr;        // pinned host buffer for the per-window sums
     bool busy = false;
     int curve = 0, suite = 0; bool expanded = false; u32 c = 0, nwin = 0, W = 0; u32 seq = 0;
+    u32 red_kh = 0, red_kl = 0;   // expanded sets: h_sums holds the pieces of the marginal-sum bucket reduction (msm_driver.h bitsum_combine)
     float ms[2] = {0.f, 0.f};
 };
 constexpr int DVN_LANES = 4;

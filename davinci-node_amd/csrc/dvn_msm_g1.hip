@@ -130,12 +130,21 @@ static int32_t windows_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, s
 static int32_t windows_collect(dvn_ctx* ctx, MsmLane& L, uint64_t* window_sums) {
     const u32 W = L.W;
     std::vector<u32> sums((size_t)(W ? W : 1) * G1::XW, 0u);
+    u32* o = (u32*)window_sums;
+    u32 w0 = 0;
     if (L.nwin) {
         TRY(lane_wait(ctx, L));
-        memcpy(sums.data(), L.h_sums, (size_t)(L.expanded ? 1 : W) * G1::XW * 4);
+        if (L.expanded) {                  // the pieces of the marginal-sum reduction -> ONE partial result in slot 0 (already R = 2^256 images)
+            typedef dvn_host::HG1 HG;
+            const HG::X r = bitsum_combine<HG>(L.h_sums, L.red_kh, L.red_kl, G1::XW);
+            if (W) {
+                if (HG::is_inf(r)) memset(o, 0, 128);
+                else { memcpy(o, r.x.l, 32); memcpy(o + 8, r.y.l, 32); memcpy(o + 16, r.zz.l, 32); memcpy(o + 24, r.zzz.l, 32); }
+                w0 = 1;
+            }
+        } else memcpy(sums.data(), L.h_sums, (size_t)W * G1::XW * 4);
     } else L.busy = false;
-    u32* o = (u32*)window_sums;
-    for (u32 w = 0; w < W; ++w) {
+    for (u32 w = w0; w < W; ++w) {
         G1::X p = G1::load_xyzz_internal(sums.data() + (size_t)w * G1::XW);
         if (G1::is_inf(p)) { memset(o + (size_t)w * 32, 0, 128); continue; }
         Ops<Fp>::to_ext(p.x, o + w * 32); Ops<Fp>::to_ext(p.y, o + w * 32 + 8);

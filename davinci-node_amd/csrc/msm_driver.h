@@ -187,6 +187,18 @@ template <class D> static int32_t sort_attrs(int device) {
     }
     return DVN_OK;
 }
+constexpr u32 S1_TPB = 1;                     // tiles per pass-1 block of an expanded set's sort
+template <class S> static int32_t digits_hist_attr(int device) {
+    static std::mutex mu;
+    static bool done[64] = {false};
+    std::lock_guard<std::mutex> lk(mu);
+    if (device < 0 || device >= 64) return fail(DVN_ERR_INVALID_ARG, "device ordinal %d out of range", device);
+    if (!done[device]) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_digits32_hist<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        done[device] = true;
+    }
+    return DVN_OK;
+}
 static inline size_t s1_lds(u32 lb) { return ((size_t)3 * lb + 80 + 2 * ST) * 4; }
 static inline size_t s2_lds() { return ((size_t)4 * 1024 + 80 + ST) * 4 + (size_t)ST * 2; }
 
@@ -214,6 +226,7 @@ static int32_t msm_windows_staged(dvn_ctx* ctx, MsmLane& L, const dvn_points* pt
     // the device (k_batch_horner) and the batch internal xyzz results stay in d_batch_out (device).
     typedef typename PairedOf<Cv>::type KC;
     constexpr u32 LPP = Lanes<KC>::LPP;
+    constexpr size_t AW_ = AccImg<KC>::W;                 // words per raw accumulator image (bucket sums, edge partials)
     static_assert(KC::XW == Cv::XW && KC::AW == Cv::AW, "paired and ordinary images must agree");
     // row_table != NULL (batched only): the points are an expanded table, row w = 2^(c w) * P_i (n points per row, win_hi
     // rows).  The digit array has the same memory layout, but is read as ONE virtual window per vector with win_hi * n
@@ -244,12 +257,14 @@ static int32_t msm_windows_staged(dvn_ctx* ctx, MsmLane& L, const dvn_points* pt
     constexpr size_t SB = ScalarOf<Cv>::S::EW * 4;       // bytes per scalar
     if (!on_dev) cs.take(n * SB);
     cs.take(total * 2); cs.take(total * 4); cs.take(total * 2); cs.take(total * 4);      // digits, p1_ref, p1_lo, sorted
+    const u32 nblk = (tpw + S1_RPB - 1) / S1_RPB;                      // row blocks of the prefix pass over hist1, per window
     cs.take((size_t)W * tpw * lb * 4); cs.take((size_t)(3 * hbins + 4) * 4);             // hist1; bin_total, bin_base, piece_base
+    cs.take((size_t)W * nblk * lb * 4);                                                  // part
     cs.take((size_t)vb * 4 * 3); cs.take(16);                                            // counts, cursor, offsets
     cs.take((size_t)heavy_cap * 4);
     cs.take((size_t)giant_cap * 4); cs.take((size_t)giant_cap * GIANT_PIECES * Cv::XW * 4);
-    cs.take((size_t)vb * Cv::XW * 4);
-    cs.take((size_t)nseg * Cv::XW * 4); cs.take((size_t)nseg * Cv::XW * 4);
+    cs.take((size_t)vb * AW_ * 4);
+    cs.take((size_t)nseg * AW_ * 4); cs.take((size_t)nseg * AW_ * 4);
     cs.take((size_t)W * bpw * Cv::XW * 4); cs.take((size_t)W * Cv::XW * 4);
     TRY(lane_ensure_ws(L, cs.off + 8192));
     Carver cv(lane_ws_base(L));
@@ -265,6 +280,7 @@ static int32_t msm_windows_staged(dvn_ctx* ctx, MsmLane& L, const dvn_points* pt
     u32* sorted = cv.take<u32>(total);
     u32* hist1 = cv.take<u32>((size_t)W * tpw * lb);
     u32* bin_total = cv.take<u32>(3 * hbins + 4);
+    u32* part = cv.take<u32>((size_t)W * nblk * lb);
     u32* bin_base = bin_total + hbins;                                 // hbins + 1 entries
     u32* piece_base = bin_base + hbins + 1;                            // hbins + 1 entries
     u32* counts = cv.take<u32>((size_t)vb * 3);
@@ -276,10 +292,10 @@ static int32_t msm_windows_staged(dvn_ctx* ctx, MsmLane& L, const dvn_points* pt
     u32* heavy_list = cv.take<u32>(heavy_cap);
     u32* giant_list = cv.take<u32>(giant_cap);
     u32* giant_part = cv.take<u32>((size_t)giant_cap * GIANT_PIECES * Cv::XW);
-    u32* buckets = cv.take<u32>((size_t)vb * Cv::XW);
+    u32* buckets = cv.take<u32>((size_t)vb * AW_);
     const u32 max_pieces = (u32)(total / ST) + hbins;
-    u32* edge_first = cv.take<u32>((size_t)nseg * Cv::XW);
-    u32* edge_last = cv.take<u32>((size_t)nseg * Cv::XW);
+    u32* edge_first = cv.take<u32>((size_t)nseg * AW_);
+    u32* edge_last = cv.take<u32>((size_t)nseg * AW_);
     u32* partials = cv.take<u32>((size_t)W * bpw * Cv::XW);
     u32* wsums = cv.take<u32>((size_t)W * Cv::XW);
 
@@ -293,13 +309,14 @@ static int32_t msm_windows_staged(dvn_ctx* ctx, MsmLane& L, const dvn_points* pt
     if (batched) k_digits16_batched<typename ScalarOf<Cv>::S><<<(unsigned)((n_src * batch + 255) / 256), 256, 0, st>>>(d_scalars, n_src, batch, c, win_hi, digits);
     else k_digits16<typename ScalarOf<Cv>::S><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_scalars, n, c, win_lo, win_hi, digits);
     DBG_SYNC("k_digits16");
-    k_s1_hist<int16_t><<<W * tpw, 1024, (size_t)lb * 4, st>>>(digits, n, tpw, lob, lb, hist1);
+    k_s1_hist<int16_t><<<W * tpw, 1024, (size_t)lb * 4, st>>>(digits, n, tpw, 1u, lob, lb, hist1);
     DBG_SYNC("k_s1_hist");
-    k_s1_offsets<<<hbins, 256, 0, st>>>(hist1, bin_total, lb, tpw);
+    k_s1_offsets_a<<<W * nblk, lb < 1024 ? (lb < 64 ? 64 : lb) : 1024, 0, st>>>(hist1, part, lb, tpw, nblk);
+    k_s1_offsets_b<<<W, lb < 1024 ? (lb < 64 ? 64 : lb) : 1024, 0, st>>>(part, bin_total, lb, nblk);
     DBG_SYNC("k_s1_offsets");
     k_p1_scan<<<1, 1024, 0, st>>>(bin_total, bin_base, totals, hbins);
     DBG_SYNC("k_p1_scan");
-    k_s1_scatter<int16_t><<<W * tpw, 1024, s1_lds(lb), st>>>(digits, n, tpw, 1u, lob, lb, 0u, 0u, win_lo, hist1, bin_base, p1_ref, p1_lo);
+    k_s1_scatter<int16_t><<<W * tpw, 1024, s1_lds(lb), st>>>(digits, n, tpw, 1u, 1u, lob, lb, 0u, 0u, win_lo, hist1, part, nblk, bin_base, p1_ref, p1_lo);
     DBG_SYNC("k_s1_scatter");
     TRY(lane_zero(L, counts, (size_t)vb * 8, st));             // counts + cursor
     k_s2_pieces<<<1, 1024, 0, st>>>(bin_base, hbins, piece_base);
@@ -360,6 +377,26 @@ static int32_t msm_windows(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, size
 // width pts->expand_c, all accumulated into ONE bucket set.  host_sum receives ONE internal xyzz image: the partial
 // result of these windows, window weights included (partial results of different window ranges simply add up).
 // --------------------------------------------------------------------------------------------------------------------
+// Pieces the reduction of an expanded bucket set leaves for the host (k_marginal_bitsums): sr pieces for each of the kh bits of
+// the row weight, then sc pieces for each of the kl + 1 bits of the column weight.
+static inline u32 bitsum_pieces(u32 kh, u32 kl) {
+    const u32 sr = ((1u << kh) + BITSUM_SPAN - 1) / BITSUM_SPAN, sc = ((1u << kl) + BITSUM_SPAN - 1) / BITSUM_SPAN;
+    return kh * sr + (kl + 1) * sc;
+}
+// sum_j 2^(kl + j) SR_j + sum_j 2^j SC_j over those pieces, MSB first (~2 c group operations on the host)
+template <class HG> static typename HG::X bitsum_combine(const u32* h, u32 kh, u32 kl, u32 xw) {
+    const u32 sr = ((1u << kh) + BITSUM_SPAN - 1) / BITSUM_SPAN, sc = ((1u << kl) + BITSUM_SPAN - 1) / BITSUM_SPAN;
+    const u32* hc = h + (size_t)kh * sr * xw;
+    typename HG::X acc = HG::infinity();
+    for (int e = (int)(kl + kh); e >= 0; --e) {
+        acc = HG::dbl(acc);
+        if (e >= (int)kl && e - (int)kl < (int)kh)
+            for (u32 s = 0; s < sr; ++s) acc = HG::add(acc, HG::load_device(h + ((size_t)(e - kl) * sr + s) * xw));
+        if (e <= (int)kl)
+            for (u32 s = 0; s < sc; ++s) acc = HG::add(acc, HG::load_device(hc + ((size_t)e * sc + s) * xw));
+    }
+    return acc;
+}
 static inline bool use_expanded(const dvn_points* pts, size_t n) {
     return pts->expand_c != 0 && n >= ((size_t)1 << 15) && n * 4 >= pts->n;
 }
@@ -368,6 +405,7 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
                             u32 win_lo, u32 win_hi, u64 flat_lo = 0, u64 flat_hi = ~(u64)0) {
     typedef typename PairedOf<Cv>::type KC;
     constexpr u32 LPP = Lanes<KC>::LPP;
+    constexpr size_t AW_ = AccImg<KC>::W;                 // words per raw accumulator image (bucket sums, edge partials)
     const u32 c = pts->expand_c, W = win_hi - win_lo;
     const u32 nb = 1u << (c - 1);
     const u32 lob = (c - 1 + 1) / 2 < 10 ? (c - 1 + 1) / 2 : 10, lb = nb >> lob;        // balanced split of the bucket bits
@@ -376,11 +414,15 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
     if (total >= ((size_t)1 << 31) || (size_t)pts->nexp * pts->n >= ((size_t)1 << 31)) return fail(DVN_ERR_INVALID_ARG, "MSM too large for 31-bit entry references");
     const u32 seg = pick_segment<Cv>(total);
     const u32 nseg = (u32)((total + seg - 1) / seg);
-    const u32 LB8 = 8;
-    const u32 bpw = (nb + 256 * LB8 - 1) / (256 * LB8);
+    // bucket reduction by marginal sums (msm_kernels.h k_bucket_marginals): nb = RH rows x RL columns
+    const u32 kl = c / 2, kh = c - 1 - kl, RL = 1u << kl, RH = 1u << kh;
+    const u32 npieces = bitsum_pieces(kh, kl);
+    if ((size_t)npieces * Cv::XW > DVN_HSUMS_WORDS) return fail(DVN_ERR_INVALID_ARG, "too many reduction pieces for the result buffer");
     const u32 heavy_cap = (u32)(nseg / (FIX_LIGHT - 1) + 1);
     const u32 giant_cap = heavy_cap / (FIX_GIANT / FIX_LIGHT) + 1;
     const u32 tpw = (u32)((n + ST - 1) / ST);
+    const u32 gpw = (tpw + S1_TPB - 1) / S1_TPB;                     // pass 1 of the sort works on groups of S1_TPB tiles
+    if ((size_t)W * lb * 4 > 96 * 1024) return fail(DVN_ERR_INVALID_ARG, "expanded window layout needs %zu bytes of LDS histograms", (size_t)W * lb * 4);
     const u32 max_pieces = (u32)(total / ST) + lb;
     const bool on_dev = flags & DVN_MSM_SCALARS_ON_DEVICE;
 
@@ -388,13 +430,14 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
     constexpr size_t SB = ScalarOf<Cv>::S::EW * 4;       // bytes per scalar
     if (!on_dev) cs.take(n * SB);
     cs.take(total * 4); cs.take(total * 4); cs.take(total * 2); cs.take(total * 4);    // digits, p1_ref, p1_lo, sorted
-    cs.take((size_t)W * tpw * lb * 4); cs.take((size_t)(3 * lb + 4) * 4);                // hist1; bin_total, bin_base, piece_base
+    const u32 nblk = (W * gpw + S1_RPB - 1) / S1_RPB;                // row blocks of the prefix pass over hist1
+    cs.take((size_t)W * gpw * lb * 4); cs.take((size_t)nblk * lb * 4); cs.take((size_t)(3 * lb + 4) * 4);                // hist1; bin_total, bin_base, piece_base
     cs.take((size_t)nb * 4 * 3); cs.take(16);                                            // counts, cursor, offsets; totals + heavy_count
     cs.take((size_t)heavy_cap * 4);
     cs.take((size_t)giant_cap * 4); cs.take((size_t)giant_cap * GIANT_PIECES * Cv::XW * 4);
-    cs.take((size_t)nb * Cv::XW * 4);
-    cs.take((size_t)nseg * Cv::XW * 4); cs.take((size_t)nseg * Cv::XW * 4);
-    cs.take((size_t)bpw * Cv::XW * 4); cs.take((size_t)Cv::XW * 4);
+    cs.take((size_t)nb * AW_ * 4);
+    cs.take((size_t)nseg * AW_ * 4); cs.take((size_t)nseg * AW_ * 4);
+    cs.take((size_t)(RH + RL) * Cv::XW * 4); cs.take((size_t)npieces * Cv::XW * 4);
     TRY(lane_ensure_ws(L, cs.off + 8192));
     Carver cv(lane_ws_base(L));
     const u32* d_scalars;
@@ -407,7 +450,8 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
     u32* p1_ref = cv.take<u32>(total);
     unsigned short* p1_lo = cv.take<unsigned short>(total);
     u32* sorted = cv.take<u32>(total);
-    u32* hist1 = cv.take<u32>((size_t)W * tpw * lb);
+    u32* hist1 = cv.take<u32>((size_t)W * gpw * lb);
+    u32* part = cv.take<u32>((size_t)nblk * lb);
     u32* bin_total = cv.take<u32>(3 * lb + 4);
     u32* bin_base = bin_total + lb;
     u32* piece_base = bin_base + lb + 1;
@@ -420,27 +464,27 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
     u32* heavy_list = cv.take<u32>(heavy_cap);
     u32* giant_list = cv.take<u32>(giant_cap);
     u32* giant_part = cv.take<u32>((size_t)giant_cap * GIANT_PIECES * Cv::XW);
-    u32* buckets = cv.take<u32>((size_t)nb * Cv::XW);
-    u32* edge_first = cv.take<u32>((size_t)nseg * Cv::XW);
-    u32* edge_last = cv.take<u32>((size_t)nseg * Cv::XW);
-    u32* partials = cv.take<u32>((size_t)bpw * Cv::XW);
-    u32* wsum = cv.take<u32>(Cv::XW);
+    u32* buckets = cv.take<u32>((size_t)nb * AW_);
+    u32* edge_first = cv.take<u32>((size_t)nseg * AW_);
+    u32* edge_last = cv.take<u32>((size_t)nseg * AW_);
+    u32* marg = cv.take<u32>((size_t)(RH + RL) * Cv::XW);
+    u32* pieces = cv.take<u32>((size_t)npieces * Cv::XW);
 
     hipStream_t st = L.stream;
     static const bool dbg = getenv("DVN_DEBUG_SYNC") != nullptr;
     if (dbg) { fprintf(stderr, "[dvn] msm(expanded) n=%zu c=%u W=%u nb=%u lob=%u lb=%u seg=%u nseg=%u tpw=%u ws=%zu\n", n, c, W, nb, lob, lb, seg, nseg, tpw, cs.off); fflush(stderr); }
     TRY(sort_attrs<int>(ctx->device));
+    TRY(digits_hist_attr<typename ScalarOf<Cv>::S>(ctx->device));
     HIP_TRY(hipEventRecord(L.ev[0], st));
     TRY(lane_zero(L, totals, 16, st));
-    k_digits32<typename ScalarOf<Cv>::S><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_scalars, n, c, win_lo, win_hi, digits, flat_lo, flat_hi);
-    DBG_SYNC("k_digits32");
-    k_s1_hist<int><<<W * tpw, 1024, (size_t)lb * 4, st>>>(digits, n, tpw, lob, lb, hist1);
-    DBG_SYNC("k_s1_hist");
-    k_s1_offsets<<<lb, 256, 0, st>>>(hist1, bin_total, lb, W * tpw);
+    k_digits32_hist<typename ScalarOf<Cv>::S><<<gpw, 1024, (size_t)W * lb * 4, st>>>(d_scalars, n, c, win_lo, win_hi, digits, flat_lo, flat_hi, gpw, S1_TPB, lob, lb, hist1);
+    DBG_SYNC("k_digits32_hist");
+    k_s1_offsets_a<<<nblk, lb < 1024 ? (lb < 64 ? 64 : lb) : 1024, 0, st>>>(hist1, part, lb, W * gpw, nblk);
+    k_s1_offsets_b<<<1, lb < 1024 ? (lb < 64 ? 64 : lb) : 1024, 0, st>>>(part, bin_total, lb, nblk);
     DBG_SYNC("k_s1_offsets");
     k_p1_scan<<<1, 1024, 0, st>>>(bin_total, bin_base, totals, lb);
     DBG_SYNC("k_p1_scan");
-    k_s1_scatter<int><<<W * tpw, 1024, s1_lds(lb), st>>>(digits, n, tpw, 0u, lob, lb, (u32)off, (u32)pts->n, win_lo, hist1, bin_base, p1_ref, p1_lo);
+    k_s1_scatter<int><<<W * gpw, 1024, s1_lds(lb), st>>>(digits, n, gpw, S1_TPB, 0u, lob, lb, (u32)off, (u32)pts->n, win_lo, hist1, part, nblk, bin_base, p1_ref, p1_lo);
     DBG_SYNC("k_s1_scatter");
     TRY(lane_zero(L, counts, (size_t)nb * 8, st));             // counts + cursor
     k_s2_pieces<<<1, 1024, 0, st>>>(bin_base, lb, piece_base);
@@ -466,13 +510,14 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
         k_giant_final<KC><<<64, GIANT_PIECES * LPP, (size_t)GIANT_PIECES * Cv::XW * 4, st>>>(giant_list, giant_count, giant_cap, giant_part, buckets);
         DBG_SYNC("k_giant");
     }
-    k_bucket_reduce<KC><<<bpw, 256 * LPP, sh_bytes, st>>>(buckets, partials, nb, LB8, bpw);
-    DBG_SYNC("k_bucket_reduce");
-    k_window_finalize<KC><<<1, 64 * LPP, (size_t)64 * Cv::XW * 4, st>>>(partials, wsum, 1, bpw);
-    DBG_SYNC("k_window_finalize");
+    k_bucket_marginals<KC><<<RH + RL, MARG_THREADS * LPP, (size_t)MARG_THREADS * Cv::XW * 4, st>>>(buckets, marg, nb, kl);
+    DBG_SYNC("k_bucket_marginals");
+    k_marginal_bitsums<KC><<<npieces, BITSUM_THREADS * LPP, sh_bytes, st>>>(marg, pieces, nb, kl);
+    DBG_SYNC("k_marginal_bitsums");
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(L.ev[1], st));
-    HIP_TRY(hipMemcpyAsync(L.h_sums, wsum, (size_t)Cv::XW * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(L.h_sums, pieces, (size_t)npieces * Cv::XW * 4, hipMemcpyDeviceToHost, st));
+    L.red_kh = kh; L.red_kl = kl;
     return DVN_OK;
 }
 
@@ -524,6 +569,8 @@ template <class Cv> struct SlowHostG {
     static X infinity() { return Cv::infinity(); }
     static bool is_inf(const X& p) { return Cv::is_inf(p); }
     static X add(const X& a, const X& b) { return Cv::add(a, b); }
+    static X dbl(const X& a) { return Cv::dbl(a); }
+    static X load_device(const u32* w) { return Cv::load_xyzz_internal(w); }
     static X horner(const u32* sums, u32 nwin, u32 c) {
         X acc = Cv::infinity();
         for (int w = (int)nwin - 1; w >= 0; --w) {
@@ -679,7 +726,8 @@ static int32_t msm_collect(dvn_ctx* ctx, MsmLane& L, typename FastHost<Cv>::G::X
     typedef typename FastHost<Cv>::G HG;
     if (L.nwin == 0) { L.busy = false; *out = HG::infinity(); ctx->last_ms[0] = ctx->last_ms[1] = 0.f; return DVN_OK; }
     TRY(lane_wait(ctx, L));
-    *out = HG::horner(L.h_sums, L.nwin, L.c);
+    if (L.expanded) *out = bitsum_combine<HG>(L.h_sums, L.red_kh, L.red_kl, Cv::XW);
+    else *out = HG::horner(L.h_sums, L.nwin, L.c);
     return DVN_OK;
 }
 

@@ -76,6 +76,55 @@ template <class Cv> __device__ __forceinline__ void st_xyzz(const typename Cv::X
     }
 }
 
+// ---- raw accumulator images: what k_accumulate hands to the fix / reduction kernels --------------------------------------
+// A run's sum leaves the hot loop as its 29-bit limbs, one u32 each (4 coordinates x NL words; the paired Fp2 curves: the even
+// lane's 4 NL words, then the odd lane's), NOT as the packed canonical image of st_xyzz.  A flush then is a handful of stores:
+// no reduction of the loose x coordinate, no canonicalisation, no bit packing -- in the hot loop that work ran for the whole
+// wave whenever any one of its 64 lanes ended a run (about every second iteration at 2^22 points), on the consumers' side it
+// runs once per lane.  Infinity is an all-zero ZZ, as in the packed image.
+template <class Cv> struct AccImg {
+    static constexpr int NL = Cv::O::Cfg::NL;
+    static constexpr int LANE_W = 4 * NL;                             // words one lane moves
+    static constexpr int W = LANE_W * (int)Lanes<Cv>::LPP;            // words per image
+    static_assert(LANE_W % 4 == 0, "16-byte accesses");
+};
+template <class C> __device__ __forceinline__ Fe<C>& fe_limbs(Fe<C>& a) { return a; }
+template <class C> __device__ __forceinline__ Fe<C>& fe_limbs(Fe2P<C>& a) { return a.c; }
+template <class C> __device__ __forceinline__ const Fe<C>& fe_limbs(const Fe<C>& a) { return a; }
+template <class C> __device__ __forceinline__ const Fe<C>& fe_limbs(const Fe2P<C>& a) { return a.c; }
+template <class Cv> __device__ __forceinline__ void st_acc(const typename Cv::X& pt, u32* __restrict__ p) {
+    constexpr int NL = AccImg<Cv>::NL, LW = AccImg<Cv>::LANE_W;
+    u32 w[LW];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        w[i] = fe_limbs(pt.x).v[i]; w[NL + i] = fe_limbs(pt.y).v[i];
+        w[2 * NL + i] = fe_limbs(pt.zz).v[i]; w[3 * NL + i] = fe_limbs(pt.zzz).v[i];
+    }
+    u32* q = p;
+    if constexpr (Lanes<Cv>::LPP == 2) q += pair_odd() * LW;
+#pragma unroll
+    for (int i = 0; i < LW; i += 4) *reinterpret_cast<uint4*>(q + i) = make_uint4(w[i], w[i + 1], w[i + 2], w[i + 3]);
+}
+template <class Cv> __device__ __forceinline__ typename Cv::X ld_acc(const u32* __restrict__ p) {
+    constexpr int NL = AccImg<Cv>::NL, LW = AccImg<Cv>::LANE_W;
+    typedef typename Cv::O::Cfg C;
+    const u32* q = p;
+    if constexpr (Lanes<Cv>::LPP == 2) q += pair_odd() * LW;
+    u32 w[LW];
+#pragma unroll
+    for (int i = 0; i < LW; i += 4) { const uint4 v = *reinterpret_cast<const uint4*>(q + i); w[i] = v.x; w[i + 1] = v.y; w[i + 2] = v.z; w[i + 3] = v.w; }
+    typename Cv::X pt;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        fe_limbs(pt.x).v[i] = w[i]; fe_limbs(pt.y).v[i] = w[NL + i];
+        fe_limbs(pt.zz).v[i] = w[2 * NL + i]; fe_limbs(pt.zzz).v[i] = w[3 * NL + i];
+    }
+    if (Cv::is_inf(pt)) return Cv::infinity();
+    // the lazily reduced accumulator leaves x below 8p: back to the weak form the general group law stores and compares
+    if constexpr (Cv::O::LAZY) fe_limbs(pt.x) = fe_reduce_full<C>(fe_limbs(pt.x));
+    return pt;
+}
+
 // ---- points: external gnark image -> internal image, in place ------------------------------------------
 template <class Cv> __global__ void k_points_to_internal(u32* __restrict__ pts, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -246,43 +295,6 @@ template <class Cv> __global__ void k_points_expand(u32* __restrict__ table, siz
         store_words16(table + ((size_t)w * n + i) * Cv::AW, wds, Cv::AW);
     }
 }
-// signed c-bit digits (c <= 24) as int32: digits[(w - win_lo) * n + i] in [-2^(c-1), 2^(c-1) - 1]
-// flat_lo / flat_hi: only the entries whose flat position win * n + i lies in [flat_lo, flat_hi) are kept, the others become
-// zero digits (no entry): an MSM over an expanded table is shared between GPUs by entry count, not by whole rows
-template <class S> __global__ void k_digits32(const u32* __restrict__ scalars, size_t n, u32 c, u32 win_lo, u32 win_hi, int* __restrict__ digits,
-                                              u64 flat_lo, u64 flat_hi) {
-    constexpr int EW = S::EW;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    u32 w[EW];
-    load_words16(scalars + i * EW, w, EW);
-    Fe<S> k = fe_ext_mont_to_canonical<S>(w);
-    u32 kw[EW + 1];
-    {
-        u32 t[EW]; fe_pack<S>(k, t);
-#pragma unroll
-        for (int j = 0; j < EW; ++j) kw[j] = t[j];
-        kw[EW] = 0;
-    }
-    const u32 nb = 1u << (c - 1), mask = (1u << c) - 1;
-    u32 carry = 0;
-    for (u32 win = 0; win < win_hi; ++win) {
-        const u32 bit = win * c;
-        u32 d = carry;
-        if (bit < 32 * EW) {
-            const u32 wi = bit >> 5, sh = bit & 31;
-            u64 two = (u64)kw[wi] | ((u64)kw[wi + 1] << 32);
-            d += (u32)(two >> sh) & mask;
-        }
-        carry = 0;
-        int v = (int)d;
-        if (d >= nb) { v = (int)d - (int)(1u << c); carry = 1; }
-        if (win >= win_lo) {
-            const u64 flat = (u64)win * n + i;
-            digits[(size_t)(win - win_lo) * n + i] = (flat >= flat_lo && flat < flat_hi) ? v : 0;
-        }
-    }
-}
 // single block: bin_base = exclusive scan of bin_total (hb <= 2048), bin_base[hb] = totals[0] = number of entries
 static __global__ __launch_bounds__(1024) void k_p1_scan(const u32* __restrict__ bin_total, u32* __restrict__ bin_base,
                                                          u32* __restrict__ totals, u32 hb) {
@@ -338,15 +350,16 @@ __device__ __forceinline__ u32 block_excl_scan(u32 v, u32* wsum, u32* total) {
 }
 template <class D> __device__ __forceinline__ u32 digit_bucket(D d) { const int v = (int)d; return (u32)(v < 0 ? -v : v) - 1; }
 
-// pass 1a, block = tile (w, t): histogram of the tile over its key-window's lb bins
-template <class D> __global__ __launch_bounds__(1024) void k_s1_hist(const D* __restrict__ digits, size_t n, u32 tpw, u32 lob, u32 lb,
+// pass 1a, block = group (w, g) of tpb consecutive tiles of window w (gpw groups per window): histogram of the group over its
+// key-window's lb bins.  One histogram row per GROUP, not per tile: the row array (and the prefix pass over it) shrinks by tpb.
+template <class D> __global__ __launch_bounds__(1024) void k_s1_hist(const D* __restrict__ digits, size_t n, u32 gpw, u32 tpb, u32 lob, u32 lb,
                                                                    u32* __restrict__ hist1) {
     extern __shared__ __align__(16) u32 sm[];
-    const u32 w = blockIdx.x / tpw, t = blockIdx.x % tpw;
+    const u32 w = blockIdx.x / gpw, g = blockIdx.x % gpw;
     for (u32 b = threadIdx.x; b < lb; b += blockDim.x) sm[b] = 0;
     __syncthreads();
-    const size_t lo = (size_t)t * ST;
-    const u32 cnt = (u32)min((size_t)ST, n - lo);
+    const size_t lo = (size_t)g * tpb * ST;
+    const u32 cnt = (u32)min((size_t)tpb * ST, n - lo);
     const D* dg = digits + (size_t)w * n + lo;
     for (u32 e = threadIdx.x; e < cnt; e += blockDim.x) {
         const D d = dg[e];
@@ -355,69 +368,137 @@ template <class D> __global__ __launch_bounds__(1024) void k_s1_hist(const D* __
     __syncthreads();
     for (u32 b = threadIdx.x; b < lb; b += blockDim.x) hist1[(size_t)blockIdx.x * lb + b] = sm[b];
 }
-// pass 1b, block = (kw, bin): exclusive prefix of hist1 over the tk tiles of key-window kw (in place); bin_total
-static __global__ __launch_bounds__(256) void k_s1_offsets(u32* __restrict__ hist1, u32* __restrict__ bin_total, u32 lb, u32 tk) {
-    __shared__ u32 part[256];
-    const u32 kw = blockIdx.x / lb, bin = blockIdx.x % lb, t = threadIdx.x, T = blockDim.x;
-    u32* h = hist1 + (size_t)kw * tk * lb + bin;
-    const u32 per = (tk + T - 1) / T;
-    const u32 lo = min(t * per, tk), hi = min(lo + per, tk);
-    u32 s = 0;
-    for (u32 k = lo; k < hi; ++k) s += h[(size_t)k * lb];
-    part[t] = s;
-    __syncthreads();
-    for (u32 d = 1; d < T; d <<= 1) {
-        u32 v = (t >= d) ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    u32 run = part[t] - s;
-    for (u32 k = lo; k < hi; ++k) { const u32 v = h[(size_t)k * lb]; h[(size_t)k * lb] = run; run += v; }
-    if (t == T - 1) bin_total[blockIdx.x] = part[t];
-}
-// pass 1c: LDS-staged scatter.  LDS: lh[lb], lbase[lb], gbase[lb], wsum[80], st_ref[ST], st_aux[ST]
-template <class D> __global__ __launch_bounds__(1024) void k_s1_scatter(const D* __restrict__ digits, size_t n, u32 tpw, u32 keyed, u32 lob, u32 lb,
-                                                                      u32 ref_base, u32 row_stride, u32 win_lo,
-                                                                      const u32* __restrict__ hist1, const u32* __restrict__ bin_base,
-                                                                      u32* __restrict__ p1_ref, unsigned short* __restrict__ p1_lo) {
+// Expanded sets: signed c-bit digits (c <= 24) as int32, digits[(w - win_lo) * n + i] in [-2^(c-1), 2^(c-1) - 1].
+// flat_lo / flat_hi: only the entries whose flat position win * n + i lies in [flat_lo, flat_hi) are kept, the others become
+// zero digits (no entry): an MSM over an expanded table is shared between GPUs by entry count, not by whole rows.
+// Digit extraction with pass 1a of the sort folded in: block g takes tpb * ST consecutive scalars, writes ALL their
+// windows' digits and keeps one LDS histogram per window, so the digit array is not read back for the histogram.
+// hist1 row of (window w, group g) = (w * gpw + g), as k_s1_hist writes it.  LDS: W * lb words.
+template <class S> __global__ __launch_bounds__(1024) void k_digits32_hist(const u32* __restrict__ scalars, size_t n, u32 c, u32 win_lo, u32 win_hi,
+                                                                         int* __restrict__ digits, u64 flat_lo, u64 flat_hi,
+                                                                         u32 gpw, u32 tpb, u32 lob, u32 lb, u32* __restrict__ hist1) {
+    constexpr int EW = S::EW;
     extern __shared__ __align__(16) u32 sm[];
-    u32 *lh = sm, *lbase = lh + lb, *gbase = lbase + lb, *wsum = gbase + lb, *st_ref = wsum + 80, *st_aux = st_ref + ST;
-    const u32 w = blockIdx.x / tpw, t = blockIdx.x % tpw, kw = keyed ? w : 0, tid = threadIdx.x;
-    for (u32 b = tid; b < lb; b += blockDim.x) lh[b] = 0;
+    const u32 W = win_hi - win_lo, g = blockIdx.x, tid = threadIdx.x;
+    for (u32 j = tid; j < W * lb; j += blockDim.x) sm[j] = 0;
     __syncthreads();
-    const size_t lo = (size_t)t * ST;
-    const u32 cnt = (u32)min((size_t)ST, n - lo);
-    const D* dg = digits + (size_t)w * n + lo;
-    int dv[ST / 1024]; u32 rk[ST / 1024];
+    const size_t lo = (size_t)g * tpb * ST, hi = min(n, lo + (size_t)tpb * ST);
+    const u32 nb = 1u << (c - 1), mask = (1u << c) - 1;
+    for (size_t i = lo + tid; i < hi; i += blockDim.x) {
+        u32 w[EW];
+        load_words16(scalars + i * EW, w, EW);
+        Fe<S> k = fe_ext_mont_to_canonical<S>(w);
+        u32 kw[EW + 1];
+        {
+            u32 t[EW]; fe_pack<S>(k, t);
 #pragma unroll
-    for (u32 j = 0; j < ST / 1024; ++j) {
-        const u32 e = j * 1024 + tid;
-        const int d = e < cnt ? (int)dg[e] : 0;
-        dv[j] = d; rk[j] = 0;
-        if (d) rk[j] = atomicAdd(&lh[digit_bucket(d) >> lob], 1u);
-    }
-    __syncthreads();
-    u32 tot;
-    const u32 ex = block_excl_scan(tid < lb ? lh[tid] : 0u, wsum, &tot);          // lb <= 1024
-    if (tid < lb) { lbase[tid] = ex; gbase[tid] = bin_base[(size_t)kw * lb + tid] + hist1[(size_t)blockIdx.x * lb + tid] - ex; }
-    __syncthreads();
-    const u32 lomask = (1u << lob) - 1;
-    const u32 rbase = ref_base + (win_lo + w) * row_stride + (u32)lo;
-#pragma unroll
-    for (u32 j = 0; j < ST / 1024; ++j) {
-        const int d = dv[j];
-        if (d) {
-            const u32 bucket = digit_bucket(d), bin = bucket >> lob, slot = lbase[bin] + rk[j];
-            st_ref[slot] = (rbase + j * 1024 + tid) | (d < 0 ? SIGN_BIT : 0u);
-            st_aux[slot] = (bin << 16) | (bucket & lomask);
+            for (int j = 0; j < EW; ++j) kw[j] = t[j];
+            kw[EW] = 0;
+        }
+        u32 carry = 0;
+        for (u32 win = 0; win < win_hi; ++win) {
+            const u32 bit = win * c;
+            u32 d = carry;
+            if (bit < 32 * EW) {
+                const u32 wi = bit >> 5, sh = bit & 31;
+                u64 two = (u64)kw[wi] | ((u64)kw[wi + 1] << 32);
+                d += (u32)(two >> sh) & mask;
+            }
+            carry = 0;
+            int v = (int)d;
+            if (d >= nb) { v = (int)d - (int)(1u << c); carry = 1; }
+            if (win >= win_lo) {
+                const u64 flat = (u64)win * n + i;
+                if (!(flat >= flat_lo && flat < flat_hi)) v = 0;
+                digits[(size_t)(win - win_lo) * n + i] = v;
+                if (v) atomicAdd(&sm[(win - win_lo) * lb + (digit_bucket(v) >> lob)], 1u);
+            }
         }
     }
     __syncthreads();
-    for (u32 s = tid; s < tot; s += blockDim.x) {
-        const u32 aux = st_aux[s], ga = gbase[aux >> 16] + s;
-        p1_ref[ga] = st_ref[s];
-        p1_lo[ga] = (unsigned short)aux;
+    for (u32 j = tid; j < W * lb; j += blockDim.x) hist1[((size_t)(j / lb) * gpw + g) * lb + (j % lb)] = sm[j];
+}
+// pass 1b: exclusive prefix of hist1 over the tk rows (tile groups) of every key-window, per bin, in two coalesced steps
+// (a thread owns a bin, so consecutive lanes read consecutive words of a row):
+//   k_s1_offsets_a  block (kw, j) walks rows [j * S1_RPB, (j + 1) * S1_RPB) of key-window kw: every row is replaced by the
+//                   prefix inside the block, the block's column sums go to part[(kw * nblk + j) * lb + bin]
+//   k_s1_offsets_b  block kw turns part[] into exclusive prefixes over j and writes bin_total[kw * lb + bin]
+// The position of (row r, bin) inside its bin's segment is then hist1[r][bin] + part[r / S1_RPB][bin] (k_s1_scatter adds them).
+constexpr u32 S1_RPB = 64;
+static __global__ __launch_bounds__(1024) void k_s1_offsets_a(u32* __restrict__ hist1, u32* __restrict__ part, u32 lb, u32 tk, u32 nblk) {
+    const u32 kw = blockIdx.x / nblk, j = blockIdx.x % nblk;
+    const u32 r0 = j * S1_RPB, r1 = min(tk, r0 + S1_RPB);
+    for (u32 bin = threadIdx.x; bin < lb; bin += blockDim.x) {
+        u32* h = hist1 + ((size_t)kw * tk + r0) * lb + bin;
+        u32 run = 0;
+        for (u32 r = r0; r < r1; ++r, h += lb) { const u32 v = *h; *h = run; run += v; }
+        part[(size_t)blockIdx.x * lb + bin] = run;
+    }
+}
+static __global__ __launch_bounds__(1024) void k_s1_offsets_b(u32* __restrict__ part, u32* __restrict__ bin_total, u32 lb, u32 nblk) {
+    const u32 kw = blockIdx.x;
+    for (u32 bin = threadIdx.x; bin < lb; bin += blockDim.x) {
+        u32* q = part + (size_t)kw * nblk * lb + bin;
+        u32 run = 0;
+        for (u32 j = 0; j < nblk; ++j, q += lb) { const u32 v = *q; *q = run; run += v; }
+        bin_total[(size_t)kw * lb + bin] = run;
+    }
+}
+// pass 1c: LDS-staged scatter, block = group (w, g) as in pass 1a; the group's tiles go through LDS one after the other, the
+// per-bin write position carried from tile to tile.  LDS: lh[lb], lbase[lb], gbase[lb], wsum[80], st_ref[ST], st_aux[ST]
+template <class D> __global__ __launch_bounds__(1024) void k_s1_scatter(const D* __restrict__ digits, size_t n, u32 gpw, u32 tpb, u32 keyed, u32 lob, u32 lb,
+                                                                      u32 ref_base, u32 row_stride, u32 win_lo,
+                                                                      const u32* __restrict__ hist1, const u32* __restrict__ part, u32 nblk,
+                                                                      const u32* __restrict__ bin_base,
+                                                                      u32* __restrict__ p1_ref, unsigned short* __restrict__ p1_lo) {
+    extern __shared__ __align__(16) u32 sm[];
+    u32 *lh = sm, *lbase = lh + lb, *gbase = lbase + lb, *wsum = gbase + lb, *st_ref = wsum + 80, *st_aux = st_ref + ST;
+    const u32 w = blockIdx.x / gpw, g = blockIdx.x % gpw, kw = keyed ? w : 0, tid = threadIdx.x;
+    // row of this block inside its key-window's prefix (keyed: the window's own gpw rows; one bucket set: all W * gpw rows)
+    const u32 row = keyed ? g : blockIdx.x;
+    if (tid < lb) gbase[tid] = bin_base[(size_t)kw * lb + tid] + hist1[(size_t)blockIdx.x * lb + tid]
+                               + part[((size_t)kw * nblk + row / S1_RPB) * lb + tid];                          // lb <= 1024
+    const u32 lomask = (1u << lob) - 1;
+    const size_t glo = (size_t)g * tpb * ST;
+    for (u32 tt = 0; tt < tpb; ++tt) {
+        const size_t lo = glo + (size_t)tt * ST;
+        if (lo >= n) break;
+        for (u32 b = tid; b < lb; b += blockDim.x) lh[b] = 0;
+        __syncthreads();
+        const u32 cnt = (u32)min((size_t)ST, n - lo);
+        const D* dg = digits + (size_t)w * n + lo;
+        int dv[ST / 1024]; u32 rk[ST / 1024];
+#pragma unroll
+        for (u32 j = 0; j < ST / 1024; ++j) {
+            const u32 e = j * 1024 + tid;
+            const int d = e < cnt ? (int)dg[e] : 0;
+            dv[j] = d; rk[j] = 0;
+            if (d) rk[j] = atomicAdd(&lh[digit_bucket(d) >> lob], 1u);
+        }
+        __syncthreads();
+        u32 tot;
+        const u32 mine = tid < lb ? lh[tid] : 0u;
+        const u32 ex = block_excl_scan(mine, wsum, &tot);
+        if (tid < lb) lbase[tid] = ex;
+        __syncthreads();
+        const u32 rbase = ref_base + (win_lo + w) * row_stride + (u32)lo;
+#pragma unroll
+        for (u32 j = 0; j < ST / 1024; ++j) {
+            const int d = dv[j];
+            if (d) {
+                const u32 bucket = digit_bucket(d), bin = bucket >> lob, slot = lbase[bin] + rk[j];
+                st_ref[slot] = (rbase + j * 1024 + tid) | (d < 0 ? SIGN_BIT : 0u);
+                st_aux[slot] = (bin << 16) | (bucket & lomask);
+            }
+        }
+        __syncthreads();
+        for (u32 s = tid; s < tot; s += blockDim.x) {
+            const u32 aux = st_aux[s], bin = aux >> 16, ga = gbase[bin] + (s - lbase[bin]);
+            p1_ref[ga] = st_ref[s];
+            p1_lo[ga] = (unsigned short)aux;
+        }
+        __syncthreads();
+        if (tid < lb) gbase[tid] += mine;                 // the next tile of the group continues where this one ended
     }
 }
 // pass 2 works on PIECES: piece = up to ST consecutive entries of one bin's segment, every bin has at least one (so
@@ -549,10 +630,10 @@ __global__ __launch_bounds__(128, AccMinBlocks<Cv>::value) void k_accumulate(con
     // max-run-length times per run and double the instruction count).
     auto flush = [&](u32 end_x) {
         u32* dst;
-        if (b_start >= pos0 && b_end <= pos1) dst = bucket_sums + ((size_t)w * nb + b) * Cv::XW;
-        else if (b_start <= pos0) dst = edge_first + ((size_t)w * nseg + k) * Cv::XW;
-        else dst = edge_last + ((size_t)w * nseg + k) * Cv::XW;
-        st_xyzz<Cv>(Cv::acc_normalize(acc), dst);
+        if (b_start >= pos0 && b_end <= pos1) dst = bucket_sums + ((size_t)w * nb + b) * AccImg<Cv>::W;
+        else if (b_start <= pos0) dst = edge_first + ((size_t)w * nseg + k) * AccImg<Cv>::W;
+        else dst = edge_last + ((size_t)w * nseg + k) * AccImg<Cv>::W;
+        st_acc<Cv>(acc, dst);
         (void)end_x;
     };
 #ifndef DVN_ACC_PREFETCH
@@ -623,8 +704,8 @@ __global__ __launch_bounds__(128) void k_fix(const u32* __restrict__ offsets, co
     if (g >= (size_t)nwin_local * nb) return;
     const u32 w = (u32)(g / nb);
     const u32 c = counts[g];
-    u32* dst = bucket_sums + g * Cv::XW;
-    if (c == 0) { st_xyzz<Cv>(Cv::infinity(), dst); return; }
+    u32* dst = bucket_sums + g * AccImg<Cv>::W;
+    if (c == 0) { st_acc<Cv>(Cv::infinity(), dst); return; }
     const u32 o = offsets[g], e = o + c;
     const u32 ks = o / seg, ke = (e - 1) / seg;
     if (ks == ke) return;                       // complete inside one segment: written by k_accumulate
@@ -635,11 +716,11 @@ __global__ __launch_bounds__(128) void k_fix(const u32* __restrict__ offsets, co
         }
         return;
     }
-    const u32* first = edge_first + (size_t)w * nseg * Cv::XW;
-    const u32* last = edge_last + (size_t)w * nseg * Cv::XW;
-    X acc = ld_xyzz<Cv>(((o % seg) == 0 ? first : last) + (size_t)ks * Cv::XW);
-    for (u32 k = ks + 1; k <= ke; ++k) acc = Cv::add(acc, ld_xyzz<Cv>(first + (size_t)k * Cv::XW));
-    st_xyzz<Cv>(acc, dst);
+    const u32* first = edge_first + (size_t)w * nseg * AccImg<Cv>::W;
+    const u32* last = edge_last + (size_t)w * nseg * AccImg<Cv>::W;
+    X acc = ld_acc<Cv>(((o % seg) == 0 ? first : last) + (size_t)ks * AccImg<Cv>::W);
+    for (u32 k = ks + 1; k <= ke; ++k) acc = Cv::add(acc, ld_acc<Cv>(first + (size_t)k * AccImg<Cv>::W));
+    st_acc<Cv>(acc, dst);
 }
 
 // block-cooperative sum of points in shared memory (blockDim.x power of two <= 256); result in lane 0.
@@ -675,15 +756,15 @@ __global__ __launch_bounds__(256 * Lanes<Cv>::LPP) void k_fix_heavy(const u32* _
             if (threadIdx.x == 0) { const u32 slot = atomicAdd(giant_count, 1u); if (slot < giant_cap) giant_list[slot] = g; }
             continue;
         }
-        const u32* first = edge_first + (size_t)w * nseg * Cv::XW;
-        const u32* last = edge_last + (size_t)w * nseg * Cv::XW;
+        const u32* first = edge_first + (size_t)w * nseg * AccImg<Cv>::W;
+        const u32* last = edge_last + (size_t)w * nseg * AccImg<Cv>::W;
         X acc = Cv::infinity();
         for (u32 k = ks + ltid<Cv>(); k <= ke; k += lbdim<Cv>()) {
             const u32* src = (k == ks && (o % seg) != 0) ? last : first;
-            acc = Cv::add(acc, ld_xyzz<Cv>(src + (size_t)k * Cv::XW));
+            acc = Cv::add(acc, ld_acc<Cv>(src + (size_t)k * AccImg<Cv>::W));
         }
         acc = block_sum<Cv>(acc, sh);
-        if (ltid<Cv>() == 0) st_xyzz<Cv>(acc, bucket_sums + (size_t)g * Cv::XW);
+        if (ltid<Cv>() == 0) st_acc<Cv>(acc, bucket_sums + (size_t)g * AccImg<Cv>::W);
         __syncthreads();
     }
 }
@@ -706,12 +787,12 @@ __global__ __launch_bounds__(256 * Lanes<Cv>::LPP) void k_giant_partial(const u3
         const u32 ks = o / seg, ke = (e - 1) / seg;
         const u32 per = (ke - ks + GIANT_PIECES) / GIANT_PIECES;          // ceil((ke - ks + 1) / GIANT_PIECES)
         const u32 k0 = ks + piece * per, k1 = min(k0 + per, ke + 1);
-        const u32* first = edge_first + (size_t)w * nseg * Cv::XW;
-        const u32* last = edge_last + (size_t)w * nseg * Cv::XW;
+        const u32* first = edge_first + (size_t)w * nseg * AccImg<Cv>::W;
+        const u32* last = edge_last + (size_t)w * nseg * AccImg<Cv>::W;
         X acc = Cv::infinity();
         for (u32 k = k0 + ltid<Cv>(); k < k1; k += lbdim<Cv>()) {
             const u32* src = (k == ks && (o % seg) != 0) ? last : first;
-            acc = Cv::add(acc, ld_xyzz<Cv>(src + (size_t)k * Cv::XW));
+            acc = Cv::add(acc, ld_acc<Cv>(src + (size_t)k * AccImg<Cv>::W));
         }
         acc = block_sum<Cv>(acc, sh);
         if (ltid<Cv>() == 0) st_xyzz<Cv>(acc, giant_part + (size_t)it * Cv::XW);
@@ -726,7 +807,7 @@ __global__ __launch_bounds__(64 * Lanes<Cv>::LPP) void k_giant_final(const u32* 
     for (u32 h = blockIdx.x; h < ng; h += gridDim.x) {             // logical block size == GIANT_PIECES
         typename Cv::X acc = ld_xyzz<Cv>(giant_part + ((size_t)h * GIANT_PIECES + ltid<Cv>()) * Cv::XW);
         acc = block_sum<Cv>(acc, sh);
-        if (ltid<Cv>() == 0) st_xyzz<Cv>(acc, bucket_sums + (size_t)giant_list[h] * Cv::XW);
+        if (ltid<Cv>() == 0) st_acc<Cv>(acc, bucket_sums + (size_t)giant_list[h] * AccImg<Cv>::W);
         __syncthreads();
     }
 }
@@ -743,9 +824,9 @@ __global__ __launch_bounds__(256 * Lanes<Cv>::LPP) void k_bucket_reduce(const u3
     X run = Cv::infinity(), tot = Cv::infinity();
     if (first < nb) {
         const u32 last = min(first + L, nb);
-        const u32* base = bucket_sums + (size_t)w * nb * Cv::XW;
+        const u32* base = bucket_sums + (size_t)w * nb * AccImg<Cv>::W;
         for (u32 b = last; b-- > first;) {
-            run = Cv::add(run, ld_xyzz<Cv>(base + (size_t)b * Cv::XW));
+            run = Cv::add(run, ld_acc<Cv>(base + (size_t)b * AccImg<Cv>::W));
             tot = Cv::add(tot, run);
         }
         // tot = sum_j (j - first + 1) * B_j ; bucket j (0-based) has weight j + 1 = (j - first + 1) + first
@@ -767,6 +848,56 @@ __global__ __launch_bounds__(64 * Lanes<Cv>::LPP) void k_window_finalize(const u
     acc = block_sum<Cv>(acc, sh);
     if (ltid<Cv>() == 0) st_xyzz<Cv>(acc, window_sums + (size_t)w * Cv::XW);
     (void)nwin_local;
+}
+
+// ---- bucket reduction of ONE large bucket set (expanded point sets: 2^15 .. 2^20 buckets), without running sums --------
+// sum_b (b + 1) B_b with b = hi * RL + lo (RL = 2^kl columns, RH = nb / RL rows) splits into two plain marginal sums,
+//     RL * sum_hi hi * R_hi  +  sum_lo (lo + 1) * C_lo,      R_hi = sum_lo B[hi][lo],   C_lo = sum_hi B[hi][lo],
+// and a weighted sum over <= 1024 marginals splits by the bits of the weight into plain subset sums,
+//     sum_e w_e M_e = sum_j 2^j * (sum over the e whose weight has bit j set of M_e).
+// Every step is a plain sum (a short serial run per thread + one LDS tree), so the dependent chain is ~25 group operations
+// where chunked running sums with their small scalar multiplications need ~60; the 2^j weights are applied on the host
+// (msm_driver.h bitsum_combine), which gets kh + kl + 1 subset sums in a few pieces each.
+// k_bucket_marginals: block b < RH sums row b, block RH + lo sums column lo; marg[b] receives the result.
+constexpr u32 MARG_THREADS = 128;
+template <class Cv>
+__global__ __launch_bounds__(MARG_THREADS * Lanes<Cv>::LPP) void k_bucket_marginals(const u32* __restrict__ bucket_sums, u32* __restrict__ marg, u32 nb, u32 kl) {
+    typedef typename Cv::X X;
+    extern __shared__ __align__(16) u32 sh[];
+    const u32 RL = 1u << kl, RH = nb >> kl;
+    const u32 t = ltid<Cv>(), T = lbdim<Cv>();
+    X acc = Cv::infinity();
+    if (blockIdx.x < RH) {
+        const u32* row = bucket_sums + (size_t)blockIdx.x * RL * AccImg<Cv>::W;
+        for (u32 i = t; i < RL; i += T) acc = Cv::add(acc, ld_acc<Cv>(row + (size_t)i * AccImg<Cv>::W));
+    } else {
+        const u32* col = bucket_sums + (size_t)(blockIdx.x - RH) * AccImg<Cv>::W;
+        for (u32 i = t; i < RH; i += T) acc = Cv::add(acc, ld_acc<Cv>(col + (size_t)i * RL * AccImg<Cv>::W));
+    }
+    acc = block_sum<Cv>(acc, sh);
+    if (t == 0) st_xyzz<Cv>(acc, marg + (size_t)blockIdx.x * Cv::XW);
+}
+// k_marginal_bitsums: the subset sums of the marginals, BITSUM_SPAN marginals per block.  Blocks [0, kh * sr) take bit
+// j = block / sr of the row index hi (weight of R_hi), the next (kl + 1) * sc blocks bit j of lo + 1 (weight of C_lo);
+// sr = ceil(RH / BITSUM_SPAN), sc = ceil(RL / BITSUM_SPAN).  out[block] receives the piece.
+constexpr u32 BITSUM_THREADS = 256, BITSUM_SPAN = 512;
+template <class Cv>
+__global__ __launch_bounds__(BITSUM_THREADS * Lanes<Cv>::LPP) void k_marginal_bitsums(const u32* __restrict__ marg, u32* __restrict__ out, u32 nb, u32 kl) {
+    typedef typename Cv::X X;
+    extern __shared__ __align__(16) u32 sh[];
+    const u32 RL = 1u << kl, RH = nb >> kl;
+    u32 kh = 0; while ((1u << kh) < RH) ++kh;
+    const u32 sr = (RH + BITSUM_SPAN - 1) / BITSUM_SPAN, sc = (RL + BITSUM_SPAN - 1) / BITSUM_SPAN;
+    const u32 t = ltid<Cv>(), T = lbdim<Cv>();
+    u32 j, s, cnt, bias; const u32* src;
+    if (blockIdx.x < kh * sr) { j = blockIdx.x / sr; s = blockIdx.x % sr; cnt = RH; bias = 0; src = marg; }
+    else { const u32 b = blockIdx.x - kh * sr; j = b / sc; s = b % sc; cnt = RL; bias = 1; src = marg + (size_t)RH * Cv::XW; }
+    X acc = Cv::infinity();
+    const u32 hi = min(cnt, (s + 1) * BITSUM_SPAN);
+    for (u32 e = s * BITSUM_SPAN + t; e < hi; e += T)
+        if (((e + bias) >> j) & 1) acc = Cv::add(acc, ld_xyzz<Cv>(src + (size_t)e * Cv::XW));
+    acc = block_sum<Cv>(acc, sh);
+    if (t == 0) st_xyzz<Cv>(acc, out + (size_t)blockIdx.x * Cv::XW);
 }
 
 // Batched MSM tail: one thread per scalar vector combines its nwin window sums MSB first (gnark's
