@@ -49,6 +49,7 @@ def load_library():
         "dvn_shutdown": (None, [vp]),
         "dvn_last_error": (C.c_char_p, [vp]),
         "dvn_version": (C.c_char_p, []),
+        "dvn_test_raise": (i32, [i32]),
         "dvn_malloc": (i32, [vp, sz, C.POINTER(vp)]),
         "dvn_free": (i32, [vp, vp]),
         "dvn_memcpy_h2d": (i32, [vp, vp, vp, sz]),
@@ -136,6 +137,9 @@ def load_library():
         "dvn_bw6761_groth16_pk_export_arrays": (i32, [vp, vp, C.c_int, vp, sz, C.POINTER(sz)]),
         "dvn_r1cs_synthetic_committed": (i32, [u64, u32, u32, u32, C.POINTER(vp)]),
         "dvn_groth16_prove_committed": (i32, [vp, vp, vp, u32, vp, vp, vp, vp, vp, vp]),
+        "dvn_groth16_prove_committed_shard": (i32, [vp, vp, vp, u32, u32, u32, vp, vp, vp, vp]),
+        "dvn_groth16_prove_committed_multi": (i32, [vp, vp, u32, vp, vp, vp, vp, vp, vp, vp]),
+        "dvn_groth16_proof_words": (i32, [vp, C.POINTER(sz)]),
         "dvn_keccak256": (i32, [vp, sz, vp]),
         "dvn_kzg_setup_load": (i32, [vp, vp, vp, C.POINTER(vp)]),
         "dvn_kzg_setup_free": (i32, [vp, vp]),
@@ -195,7 +199,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = [
-    "dvn_init", "dvn_shutdown", "dvn_last_error", "dvn_version", "dvn_malloc", "dvn_free", "dvn_memcpy_h2d",
+    "dvn_init", "dvn_shutdown", "dvn_last_error", "dvn_version", "dvn_test_raise", "dvn_malloc", "dvn_free", "dvn_memcpy_h2d",
     "dvn_memcpy_d2h", "dvn_synchronize", "dvn_points_upload_g1", "dvn_points_upload_g2", "dvn_points_synthetic_g1",
     "dvn_points_synthetic_g2", "dvn_scalars_synthetic", "dvn_points_set_expanded", "dvn_points_download", "dvn_points_len", "dvn_points_free", "dvn_msm_g1", "dvn_msm_g1_static", "dvn_msm_g2", "dvn_msm_g1_batched",
     "dvn_msm_g1_submit", "dvn_msm_g1_collect", "dvn_msm_g2_submit", "dvn_msm_g2_collect", "dvn_msm_plan", "dvn_msm_plan_points", "dvn_msm_g1_windows", "dvn_msm_g1_windows_submit", "dvn_msm_g1_windows_collect", "dvn_msm_combine_g1", "dvn_ntt_domain", "dvn_ntt_domain_free", "dvn_ntt",
@@ -208,7 +212,7 @@ EXPORTED_SYMBOLS = [
     "dvn_bls12381_points_upload_g1", "dvn_bls12381_points_upload_g2", "dvn_bls12381_points_synthetic_g1", "dvn_bls12381_points_download",
     "dvn_bls12381_scalars_synthetic", "dvn_bls12381_msm_g1", "dvn_bls12381_msm_g2", "dvn_bls12381_ntt_domain", "dvn_bls12381_ntt", "dvn_bls12381_groth16_compute_h",
     "dvn_bls12381_r1cs_synthetic", "dvn_bls12381_groth16_setup", "dvn_bls12381_groth16_prove", "dvn_r1cs_curve",
-    "dvn_r1cs_synthetic_committed", "dvn_groth16_prove_committed", "dvn_keccak256", "dvn_groth16_vk_export", "dvn_groth16_pk_import", "dvn_groth16_prove_solved", "dvn_groth16_pk_export_arrays",
+    "dvn_r1cs_synthetic_committed", "dvn_groth16_prove_committed", "dvn_groth16_prove_committed_shard", "dvn_groth16_prove_committed_multi", "dvn_groth16_proof_words", "dvn_keccak256", "dvn_groth16_vk_export", "dvn_groth16_pk_import", "dvn_groth16_prove_solved", "dvn_groth16_pk_export_arrays",
     "dvn_bls12377_groth16_pk_import", "dvn_bls12377_groth16_prove_solved", "dvn_bls12377_groth16_pk_export_arrays", "dvn_bls12381_groth16_pk_import", "dvn_bls12381_groth16_prove_solved", "dvn_bls12381_groth16_pk_export_arrays", "dvn_bw6761_groth16_pk_import", "dvn_bw6761_groth16_prove_solved", "dvn_bw6761_groth16_pk_export_arrays",
     "dvn_kzg_setup_load", "dvn_kzg_setup_free", "dvn_kzg_blob_to_commitment", "dvn_kzg_compute_proof", "dvn_kzg_compute_cell_proofs",
     "dvn_kzg_evaluate_barycentric", "dvn_kzg_compute_blob_proof", "dvn_sha256",
@@ -602,6 +606,23 @@ class Groth16Key:
         self.ctx._chk(self.ctx.L.dvn_groth16_prove_committed(self.ctx.h, self.h, wp, fl, _host(r_mont), _host(s_mont), _host(out), _host(cm), _host(pok), _host(ch)))
         return {"Ar": out[0:8].copy(), "Bs": out[8:24].copy(), "Krs": out[24:32].copy(), "Commitment": cm, "CommitmentPok": pok, "challenge": ch}
 
+    def prove_committed_shard(self, witness, rank: int, world: int) -> dict:
+        """Rank `rank` of `world` of a committed proof: the commitment hint / challenge / witness completion whole, then this
+        rank's share of the five MSMs.  'partial': (72,) uint64 to be all-gathered; the other entries are the same on all ranks."""
+        assert self.curve == "bn254"
+        out = np.zeros(72, dtype=np.uint64); cm = np.zeros(8, dtype=np.uint64); pok = np.zeros(8, dtype=np.uint64); ch = np.zeros(4, dtype=np.uint64)
+        if isinstance(witness, (int, np.integer)):
+            wp, fl = C.c_void_p(int(witness)), 1
+        else:
+            witness = np.ascontiguousarray(witness, dtype=np.uint64); wp, fl = _host(witness), 0
+        self.ctx._chk(self.ctx.L.dvn_groth16_prove_committed_shard(self.ctx.h, self.h, wp, fl, rank, world, _host(out), _host(cm), _host(pok), _host(ch)))
+        return {"partial": out, "Commitment": cm, "CommitmentPok": pok, "challenge": ch}
+
+    def proof_words(self) -> int:
+        n = C.c_size_t()
+        self.ctx._chk(self.ctx.L.dvn_groth16_proof_words(self.h, C.byref(n)))
+        return int(n.value)
+
     def prove_shard(self, witness, rank: int, world: int) -> np.ndarray:
         """This rank's partial results of the five MSMs (BN254 keys): (72,) uint64 to be all-gathered."""
         assert self.curve == "bn254"
@@ -664,6 +685,16 @@ def prove_multi(ctx: "Context", keys, witness: np.ndarray, r_mont, s_mont, solve
     return {"Ar": out[0:a1].copy(), "Bs": out[a1:a1 + a2].copy(), "Krs": out[a1 + a2:2 * a1 + a2].copy()}
 
 
+def prove_committed_multi(ctx: "Context", keys, witness: np.ndarray, r_mont, s_mont) -> dict:
+    """One committed (statetransition-shaped) BN254 proof over all devices of a multi-device context."""
+    arr = (C.c_void_p * len(keys))(*[k.h for k in keys])
+    witness = np.ascontiguousarray(witness, dtype=np.uint64)
+    r_mont = np.ascontiguousarray(r_mont, dtype=np.uint64); s_mont = np.ascontiguousarray(s_mont, dtype=np.uint64)
+    out = np.zeros(32, dtype=np.uint64); cm = np.zeros(8, dtype=np.uint64); pok = np.zeros(8, dtype=np.uint64); ch = np.zeros(4, dtype=np.uint64)
+    ctx._chk(ctx.L.dvn_groth16_prove_committed_multi(ctx.h, arr, len(keys), _host(witness), _host(r_mont), _host(s_mont), _host(out), _host(cm), _host(pok), _host(ch)))
+    return {"Ar": out[0:8].copy(), "Bs": out[8:24].copy(), "Krs": out[24:32].copy(), "Commitment": cm, "CommitmentPok": pok, "challenge": ch}
+
+
 def gnark_pk_scan(data: bytes) -> dict:
     """Host only: the section sizes of a gnark BN254 proving-key image (dvn_gnark_pk_scan)."""
     L = load_library()
@@ -693,6 +724,7 @@ class LoadedKey:
         ln = C.c_uint32(); sizes = (C.c_uint64 * 5)()
         ctx.L.dvn_groth16_pk_info(h, C.byref(ln), sizes)
         self.log_n = ln.value
+        self.sizes = dict(zip(("A", "B", "K", "Z", "B2"), (int(v) for v in sizes)))
 
     prove_solved = None     # bound below to ImportedKey.prove_solved
 

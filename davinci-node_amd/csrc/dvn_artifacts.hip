@@ -424,7 +424,7 @@ int32_t dvn_internal_key_cache_clear(dvn_ctx* ctx) {
 
 // Host only: what the file holds, without touching a device (tests on CPU; also a cheap sanity check before a load).
 // info: log_n, raw (0 / 1), n_wires, |A|, |B|, |Z|, |K|, |G2.B|, n_commitments, |Basis[0]|, domain flag byte present (0 / 1)
-extern "C" int32_t dvn_gnark_pk_scan(const uint8_t* data, size_t len, uint64_t info[11]) {
+extern "C" int32_t dvn_gnark_pk_scan(const uint8_t* data, size_t len, uint64_t info[11]) try {
     if (!data || !info) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     Layout L; std::string why;
     try {
@@ -433,18 +433,18 @@ extern "C" int32_t dvn_gnark_pk_scan(const uint8_t* data, size_t len, uint64_t i
     info[0] = L.log_n; info[1] = L.raw; info[2] = L.n_wires; info[3] = L.A.count; info[4] = L.B.count; info[5] = L.Z.count; info[6] = L.K.count;
     info[7] = L.B2.count; info[8] = L.n_commitments; info[9] = L.n_commitments ? L.basis[0].count : 0; info[10] = L.precompute_flag;
     return DVN_OK;
-}
+} DVN_CATCH
 extern "C" int32_t dvn_groth16_pk_load_bytes(dvn_ctx* ctx, const uint8_t* data, size_t len, uint32_t n_public, const uint32_t* committed_wires,
-                                             uint32_t n_committed_wires, dvn_groth16_pk** out) {
+                                             uint32_t n_committed_wires, dvn_groth16_pk** out) try {
     TRY(enter(ctx));
     if (!data || !out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     try { return load_image(ctx, data, len, n_public, committed_wires, n_committed_wires, out); }
     catch (...) { return fail(DVN_ERR_OOM, "host allocation failed while reading the key"); }
-}
+} DVN_CATCH
 // path: the artifact file; sha256_hex: its expected content hash (the file's name in the node's cache) or NULL to skip the
 // check.  A key with the same hash already resident on this context is returned as is (one upload per process).
 extern "C" int32_t dvn_groth16_pk_load_file(dvn_ctx* ctx, const char* path, const char* sha256_hex, uint32_t n_public,
-                                            const uint32_t* committed_wires, uint32_t n_committed_wires, dvn_groth16_pk** out) {
+                                            const uint32_t* committed_wires, uint32_t n_committed_wires, dvn_groth16_pk** out) try {
     TRY(enter(ctx));
     if (!path || !out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     const int fd = open(path, O_RDONLY);
@@ -487,11 +487,11 @@ extern "C" int32_t dvn_groth16_pk_load_file(dvn_ctx* ctx, const char* path, cons
     }
     munmap(map, len);
     return rc;
-}
+} DVN_CATCH
 // the commitment bases of a loaded key (NULL when the key has no commitment): what the solver's BSB22 hint passes to
 // dvn_pedersen_commit.  The handles stay owned by the key.
-extern "C" int32_t dvn_groth16_pk_commitment_bases(const dvn_groth16_pk* pk, const dvn_points** basis, const dvn_points** basis_exp_sigma) {
+extern "C" int32_t dvn_groth16_pk_commitment_bases(const dvn_groth16_pk* pk, const dvn_points** basis, const dvn_points** basis_exp_sigma) try {
     if (!pk || !basis || !basis_exp_sigma) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     *basis = pk->Basis; *basis_exp_sigma = pk->BasisSigma;
     return DVN_OK;
-}
+} DVN_CATCH

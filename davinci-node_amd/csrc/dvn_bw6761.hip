@@ -11,13 +11,13 @@
 
 static int32_t check_group(int group) { return (group == 1 || group == 2) ? DVN_OK : fail(DVN_ERR_INVALID_ARG, "group must be 1 (G1) or 2 (G2)"); }
 
-extern "C" int32_t dvn_bw6761_points_upload(dvn_ctx* ctx, int group, const uint64_t* xy, size_t n, dvn_points** out) {
+extern "C" int32_t dvn_bw6761_points_upload(dvn_ctx* ctx, int group, const uint64_t* xy, size_t n, dvn_points** out) try {
     TRY(check_group(group));
     return points_upload<G_761>(ctx, xy, n, group, out);
-}
+} DVN_CATCH
 // P_i = [s0]B + i*[s1]B with B = `base_xy` (one affine point, gnark image) and (s0, s1) the first two 256-bit
 // blocks of SplitMix64 stream `seed` (oracle/curves_py.py Suite.progression_points)
-extern "C" int32_t dvn_bw6761_points_synthetic(dvn_ctx* ctx, int group, const uint64_t base_xy[24], uint64_t seed, size_t n, dvn_points** out) {
+extern "C" int32_t dvn_bw6761_points_synthetic(dvn_ctx* ctx, int group, const uint64_t base_xy[24], uint64_t seed, size_t n, dvn_points** out) try {
     TRY(enter(ctx));
     TRY(check_group(group));
     if (!out || !base_xy) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
@@ -32,20 +32,20 @@ extern "C" int32_t dvn_bw6761_points_synthetic(dvn_ctx* ctx, int group, const ui
     if (G_761::is_inf(gen)) return fail(DVN_ERR_INVALID_ARG, "base point is the point at infinity");
     G_761::A base = G_761::to_affine(host_scalar_mul<G_761>(gen, s0)), step = G_761::to_affine(host_scalar_mul<G_761>(gen, s1));
     return points_progression<G_761>(ctx, n, group, base, step, out);
-}
-extern "C" int32_t dvn_bw6761_points_download(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, uint64_t* xy) {
+} DVN_CATCH
+extern "C" int32_t dvn_bw6761_points_download(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, uint64_t* xy) try {
     TRY(enter(ctx));
     if (!pts || (!xy && n)) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (pts->suite != 2) return fail(DVN_ERR_INVALID_ARG, "point set is not BW6-761");
     if (off > pts->n || n > pts->n - off) return fail(DVN_ERR_INVALID_ARG, "range [%zu, %zu) outside point set of %zu", off, off + n, pts->n);
     std::lock_guard<std::mutex> lk(ctx->mu);
     return points_download<G_761>(ctx, pts, off, n, xy);
-}
-extern "C" int32_t dvn_bw6761_msm(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags, uint64_t out_jac[36]) {
+} DVN_CATCH
+extern "C" int32_t dvn_bw6761_msm(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags, uint64_t out_jac[36]) try {
     if (!pts) { TRY(enter(ctx)); return fail(DVN_ERR_INVALID_ARG, "NULL argument"); }
     return msm_full<G_761>(ctx, pts, pts->curve, off, n, scalars, flags, out_jac);
-}
-extern "C" int32_t dvn_bw6761_scalars_synthetic(dvn_ctx* ctx, uint64_t seed, int kind, size_t n, void* d_out) {
+} DVN_CATCH
+extern "C" int32_t dvn_bw6761_scalars_synthetic(dvn_ctx* ctx, uint64_t seed, int kind, size_t n, void* d_out) try {
     TRY(enter(ctx));
     if (!d_out && n) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (kind != 0 && kind != 1) return fail(DVN_ERR_INVALID_ARG, "kind must be 0 (uniform) or 1 (witness-like)");
@@ -55,16 +55,16 @@ extern "C" int32_t dvn_bw6761_scalars_synthetic(dvn_ctx* ctx, uint64_t seed, int
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return DVN_OK;
-}
+} DVN_CATCH
 // ---- the scalar field's NTT (377-bit elements: 6 x uint64, two-adicity 46, coset shift 15) and computeH ------------------
-extern "C" int32_t dvn_bw6761_ntt_domain(dvn_ctx* ctx, uint32_t log_n, dvn_domain** out) { return ntt_domain_create<Fp377Cfg>(ctx, log_n, out); }
-extern "C" int32_t dvn_bw6761_ntt(dvn_ctx* ctx, const dvn_domain* dom, uint64_t* data, int inverse, int decimation, int on_coset, uint32_t flags) {
+extern "C" int32_t dvn_bw6761_ntt_domain(dvn_ctx* ctx, uint32_t log_n, dvn_domain** out) try { return ntt_domain_create<Fp377Cfg>(ctx, log_n, out); } DVN_CATCH
+extern "C" int32_t dvn_bw6761_ntt(dvn_ctx* ctx, const dvn_domain* dom, uint64_t* data, int inverse, int decimation, int on_coset, uint32_t flags) try {
     return suite_ntt<Fp377Cfg>(ctx, "BW6-761", dom, data, inverse, decimation, on_coset, flags);
-}
+} DVN_CATCH
 extern "C" int32_t dvn_bw6761_groth16_compute_h(dvn_ctx* ctx, const dvn_domain* dom, const uint64_t* a, const uint64_t* b, const uint64_t* c,
-                                                size_t len, uint64_t* h_out, uint32_t flags) {
+                                                size_t len, uint64_t* h_out, uint32_t flags) try {
     return compute_h_api<Fp377Cfg>(ctx, "BW6-761", dom, a, b, c, len, h_out, flags);
-}
+} DVN_CATCH
 
 // ---- Groth16 on BW6-761 (the aggregator proof, one per batch; reference dispatch prover/prover_gpu.go:52-57) ------------------
 // Generators of the r-torsion for the SYNTHETIC setup: [#E / r] * (smallest-x point) on y^2 = x^3 - 1 and on y^2 = x^3 + 4,
@@ -108,38 +108,38 @@ struct SuiteBw6761 {
     static int32_t msm_collect_g1(dvn_ctx* ctx, MsmLane* l, H1::X* out) { return msm_collect<G_761>(ctx, *l, out); }
     static int32_t msm_collect_g2(dvn_ctx* ctx, MsmLane* l, H2::X* out) { return msm_collect<G_761>(ctx, *l, out); }
 };
-extern "C" int32_t dvn_bw6761_r1cs_synthetic(uint64_t seed, uint32_t n_constraints, uint32_t n_public, dvn_r1cs** out) {
+extern "C" int32_t dvn_bw6761_r1cs_synthetic(uint64_t seed, uint32_t n_constraints, uint32_t n_public, dvn_r1cs** out) try {
     return r1cs_synthetic<SuiteBw6761>(seed, n_constraints, n_public, out);
-}
-extern "C" int32_t dvn_bw6761_groth16_setup(dvn_ctx* ctx, const dvn_r1cs* cs, uint64_t seed, dvn_groth16_pk** out) {
+} DVN_CATCH
+extern "C" int32_t dvn_bw6761_groth16_setup(dvn_ctx* ctx, const dvn_r1cs* cs, uint64_t seed, dvn_groth16_pk** out) try {
     return groth16_setup<SuiteBw6761>(ctx, cs, seed, out);
-}
+} DVN_CATCH
 // witness: m x 6 uint64; r_mont / s_mont: 6 uint64 each; proof_out: Ar (24) | Bs (24) | Krs (24) uint64
 extern "C" int32_t dvn_bw6761_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
-                                            const uint64_t r_mont[6], const uint64_t s_mont[6], uint64_t proof_out[72]) {
+                                            const uint64_t r_mont[6], const uint64_t s_mont[6], uint64_t proof_out[72]) try {
     return groth16_prove<SuiteBw6761>(ctx, pk, witness, flags, r_mont, s_mont, proof_out);
-}
+} DVN_CATCH
 
 // gnark's own key arrays + proofs from the solver's output on this curve (see dvn_groth16_pk_import / dvn_groth16_prove_solved)
-extern "C" int32_t dvn_bw6761_groth16_pk_import(dvn_ctx* ctx, const dvn_groth16_key_arrays* k, dvn_groth16_pk** out) { return groth16_pk_import_api<SuiteBw6761>(ctx, k, out); }
+extern "C" int32_t dvn_bw6761_groth16_pk_import(dvn_ctx* ctx, const dvn_groth16_key_arrays* k, dvn_groth16_pk** out) try { return groth16_pk_import_api<SuiteBw6761>(ctx, k, out); } DVN_CATCH
 extern "C" int32_t dvn_bw6761_groth16_prove_solved(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b, const uint64_t* c, size_t len,
-                                              const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out) {
+                                              const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out) try {
     return groth16_prove_solved<SuiteBw6761>(ctx, pk, w, a, b, c, len, r_mont, s_mont, proof_out);
-}
-extern "C" int32_t dvn_bw6761_groth16_pk_export_arrays(dvn_ctx* ctx, const dvn_groth16_pk* pk, int which, uint64_t* out, size_t cap_words, size_t* n_words) {
+} DVN_CATCH
+extern "C" int32_t dvn_bw6761_groth16_pk_export_arrays(dvn_ctx* ctx, const dvn_groth16_pk* pk, int which, uint64_t* out, size_t cap_words, size_t* n_words) try {
     return groth16_pk_export_arrays<SuiteBw6761>(ctx, pk, which, out, cap_words, n_words);
-}
+} DVN_CATCH
 // Pedersen commitment + PoK on this curve: the BSB22 commitment hint of the aggregator proof (gnark-crypto
 // ecc/bw6-761/fr/pedersen ProvingKey.Commit / ProveKnowledge); values are 6-word scalars.
 extern "C" int32_t dvn_bw6761_pedersen_commit(dvn_ctx* ctx, const dvn_points* basis, const dvn_points* basis_exp_sigma, const uint64_t* values_mont,
-                                              size_t n, uint32_t flags, uint64_t commitment_out[24], uint64_t pok_out[24]) {
+                                              size_t n, uint32_t flags, uint64_t commitment_out[24], uint64_t pok_out[24]) try {
     return pedersen_commit<SuiteBw6761>(ctx, basis, basis_exp_sigma, values_mont, n, flags, commitment_out, pok_out);
-}
+} DVN_CATCH
 // The aggregator proof over all devices of a multi-device context (see dvn_groth16_prove_solved_multi)
 extern "C" int32_t dvn_bw6761_groth16_prove_solved_multi(dvn_ctx* ctx, dvn_groth16_pk* const* keys, uint32_t nkeys, const uint64_t* w, const uint64_t* a,
                                                          const uint64_t* b, const uint64_t* c, size_t len, const uint64_t* r_mont, const uint64_t* s_mont,
-                                                         uint64_t* proof_out) {
+                                                         uint64_t* proof_out) try {
     if (!a || !b || !c) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     const uint64_t* src[3] = {a, b, c};
     return groth16_prove_multi<SuiteBw6761>(ctx, keys, nkeys, w, 0u, src, len, r_mont, s_mont, proof_out);
-}
+} DVN_CATCH

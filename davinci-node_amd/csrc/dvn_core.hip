@@ -3,6 +3,8 @@
 // /root/reference/prover/prover_gpu.go:24-61.
 #include <dlfcn.h>
 #include "dvn_internal.h"
+#include <stdexcept>
+#include <system_error>
 
 thread_local std::string tl_error;
 // ---- profiler markers (DVN_ROCTX=1): roctxRangePushA / roctxRangePop of whichever roctx library is installed -------------
@@ -31,9 +33,29 @@ void dvn_roctx_pop() { Roctx& r = roctx(); if (r.pop) (void)r.pop(); }
 int32_t fail(int32_t code, const char* fmt, ...) {
     char buf[512];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
-    tl_error = buf;
+    try { tl_error = buf; } catch (...) { /* out of memory while recording the message: the code still says what happened */ }
     return code;
 }
+
+// The one place where a C++ exception becomes an error code: every extern "C" entry point that returns a code is a
+// function-try-block ending in DVN_CATCH (dvn_internal.h), so nothing thrown below it -- std::bad_alloc from a vector or
+// string, std::system_error from a thread or std::async that cannot start -- unwinds into the C (cgo, ctypes) caller.
+int32_t dvn_guard_fail() noexcept {
+    try { throw; }
+    catch (const std::bad_alloc&) { return fail(DVN_ERR_OOM, "host allocation failed (std::bad_alloc)"); }
+    catch (const std::system_error& e) { return fail(DVN_ERR_OOM, "host resource exhausted: %s", e.what()); }
+    catch (const std::exception& e) { return fail(DVN_ERR_DEVICE, "internal error: %s", e.what()); }
+    catch (...) { return fail(DVN_ERR_DEVICE, "internal error: unknown exception"); }
+}
+// Test hook (host only, no context needed): throws the exception class `kind` names from inside a guarded entry point, so that
+// the mapping above can be exercised without exhausting memory.  0: nothing, 1: bad_alloc, 2: system_error, 3: runtime_error, 4: int.
+extern "C" int32_t dvn_test_raise(int32_t kind) try {
+    if (kind == 1) throw std::bad_alloc();
+    if (kind == 2) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again), "thread could not start");
+    if (kind == 3) throw std::runtime_error("injected");
+    if (kind == 4) throw 4;
+    return DVN_OK;
+} DVN_CATCH
 
 // ------------------------------------------------------------------------------------------------------
 // lifetime
@@ -65,7 +87,7 @@ static int32_t ctx_create(int dev, dvn_ctx** out) {
 // devs / ndev: every listed ordinal gets a context.  The handle returned serves devs[0]; the contexts of devs[1..] hang off it
 // (dvn_ctx_device) and are what the *_multi entry points spread one proof over.  An ordinal may repeat (two contexts sharing
 // one GPU): how a one-GPU box rehearses the multi-device path.
-extern "C" int32_t dvn_init(const int* devs, int ndev, dvn_ctx** out) {
+extern "C" int32_t dvn_init(const int* devs, int ndev, dvn_ctx** out) try {
     if (!out) return fail(DVN_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
     if (ndev < 0 || ndev > 64 || (ndev > 0 && !devs)) return fail(DVN_ERR_INVALID_ARG, "bad device list");
@@ -89,13 +111,13 @@ extern "C" int32_t dvn_init(const int* devs, int ndev, dvn_ctx** out) {
     (void)hipSetDevice(primary->device);
     *out = primary;
     return DVN_OK;
-}
-extern "C" int32_t dvn_ctx_device_count(const dvn_ctx* ctx) { return ctx ? 1 + (int32_t)ctx->peers.size() : 0; }
+} DVN_CATCH
+extern "C" int32_t dvn_ctx_device_count(const dvn_ctx* ctx) try { return ctx ? 1 + (int32_t)ctx->peers.size() : 0; } DVN_CATCH
 extern "C" dvn_ctx* dvn_ctx_device(dvn_ctx* ctx, int32_t index) {
     if (!ctx || index < 0 || index > (int32_t)ctx->peers.size()) { (void)fail(DVN_ERR_INVALID_ARG, "device index %d outside the context's %d devices", index, ctx ? 1 + (int)ctx->peers.size() : 0); return nullptr; }
     return index == 0 ? ctx : ctx->peers[(size_t)index - 1];
 }
-extern "C" int32_t dvn_ctx_device_ordinal(const dvn_ctx* ctx) { return ctx ? ctx->device : -1; }
+extern "C" int32_t dvn_ctx_device_ordinal(const dvn_ctx* ctx) try { return ctx ? ctx->device : -1; } DVN_CATCH
 extern "C" const char* dvn_error_string(int32_t code) {
     switch (code) {
         case DVN_OK: return "ok";
@@ -130,23 +152,23 @@ extern "C" void dvn_shutdown(dvn_ctx* ctx) {
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
-extern "C" int32_t dvn_malloc(dvn_ctx* ctx, size_t bytes, void** dptr) {
+extern "C" int32_t dvn_malloc(dvn_ctx* ctx, size_t bytes, void** dptr) try {
     TRY(enter(ctx));
     if (!dptr) return fail(DVN_ERR_INVALID_ARG, "dptr is NULL");
     HIP_TRY(hipMalloc(dptr, bytes ? bytes : 1));
     return DVN_OK;
-}
-extern "C" int32_t dvn_free(dvn_ctx* ctx, void* dptr) { TRY(enter(ctx)); if (dptr) HIP_TRY(hipFree(dptr)); return DVN_OK; }
-extern "C" int32_t dvn_memcpy_h2d(dvn_ctx* ctx, void* dst, const void* src, size_t bytes) {
+} DVN_CATCH
+extern "C" int32_t dvn_free(dvn_ctx* ctx, void* dptr) try { TRY(enter(ctx)); if (dptr) HIP_TRY(hipFree(dptr)); return DVN_OK; } DVN_CATCH
+extern "C" int32_t dvn_memcpy_h2d(dvn_ctx* ctx, void* dst, const void* src, size_t bytes) try {
     TRY(enter(ctx)); HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return DVN_OK;
-}
-extern "C" int32_t dvn_memcpy_d2h(dvn_ctx* ctx, void* dst, const void* src, size_t bytes) {
+} DVN_CATCH
+extern "C" int32_t dvn_memcpy_d2h(dvn_ctx* ctx, void* dst, const void* src, size_t bytes) try {
     TRY(enter(ctx)); HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return DVN_OK;
-}
-extern "C" int32_t dvn_synchronize(dvn_ctx* ctx) { TRY(enter(ctx)); HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipDeviceSynchronize()); return DVN_OK; }
-extern "C" int32_t dvn_last_kernel_ms(dvn_ctx* ctx, int which, float* ms) {
+} DVN_CATCH
+extern "C" int32_t dvn_synchronize(dvn_ctx* ctx) try { TRY(enter(ctx)); HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipDeviceSynchronize()); return DVN_OK; } DVN_CATCH
+extern "C" int32_t dvn_last_kernel_ms(dvn_ctx* ctx, int which, float* ms) try {
     if (!ctx || !ms || which < 0 || which > 1) return fail(DVN_ERR_INVALID_ARG, "bad argument");
     *ms = ctx->last_ms[which];
     return DVN_OK;
-}
+} DVN_CATCH
 

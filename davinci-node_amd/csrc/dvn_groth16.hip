@@ -6,62 +6,62 @@
 #include "suite_bn254.h"
 
 
-extern "C" int32_t dvn_r1cs_synthetic(uint64_t seed, uint32_t n_constraints, uint32_t n_public, dvn_r1cs** out) {
+extern "C" int32_t dvn_r1cs_synthetic(uint64_t seed, uint32_t n_constraints, uint32_t n_public, dvn_r1cs** out) try {
     return r1cs_synthetic<SuiteBn254>(seed, n_constraints, n_public, out);
-}
-extern "C" int32_t dvn_groth16_setup(dvn_ctx* ctx, const dvn_r1cs* cs, uint64_t seed, dvn_groth16_pk** out) { return groth16_setup<SuiteBn254>(ctx, cs, seed, out); }
+} DVN_CATCH
+extern "C" int32_t dvn_groth16_setup(dvn_ctx* ctx, const dvn_r1cs* cs, uint64_t seed, dvn_groth16_pk** out) try { return groth16_setup<SuiteBn254>(ctx, cs, seed, out); } DVN_CATCH
 extern "C" int32_t dvn_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
-                                     const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32]) {
+                                     const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32]) try {
     return groth16_prove<SuiteBn254>(ctx, pk, witness, flags, r_mont, s_mont, proof_out);
-}
+} DVN_CATCH
 
 // Sharded proving (BASELINE config 5: the proof's MSMs sharded across the GPUs of a node): rank `rank` of `world` computes its
 // rows of the five MSMs (dvn_groth16_prove_shard, 72 uint64 of partial results), the ranks all-gather them, and every rank (or
 // one) assembles the proof on the host (dvn_groth16_prove_combine).  Needs expanded key sets (>= 2^15 points each).
 extern "C" int32_t dvn_groth16_prove_shard(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
-                                           uint32_t rank, uint32_t world, uint64_t partial_out[72]) {
+                                           uint32_t rank, uint32_t world, uint64_t partial_out[72]) try {
     return groth16_prove_shard<SuiteBn254>(ctx, pk, witness, flags, rank, world, partial_out);
-}
+} DVN_CATCH
 extern "C" int32_t dvn_groth16_prove_combine(const dvn_groth16_pk* pk, const uint64_t* partials, uint32_t world,
-                                             const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32]) {
+                                             const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32]) try {
     return groth16_prove_combine<SuiteBn254>(pk, partials, world, r_mont, s_mont, proof_out);
-}
+} DVN_CATCH
 
 // One proof over all devices of a multi-device context (dvn_init(devs, ndev > 1)); keys[i] = the key on dvn_ctx_device(ctx, i)
 extern "C" int32_t dvn_groth16_prove_multi(dvn_ctx* ctx, dvn_groth16_pk* const* keys, uint32_t nkeys, const uint64_t* witness,
-                                           const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32]) {
+                                           const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32]) try {
     return groth16_prove_multi<SuiteBn254>(ctx, keys, nkeys, witness, 0u, nullptr, 0, r_mont, s_mont, proof_out);
-}
+} DVN_CATCH
 extern "C" int32_t dvn_groth16_prove_solved_multi(dvn_ctx* ctx, dvn_groth16_pk* const* keys, uint32_t nkeys, const uint64_t* w, const uint64_t* a,
                                                   const uint64_t* b, const uint64_t* c, size_t len, const uint64_t r_mont[4], const uint64_t s_mont[4],
-                                                  uint64_t proof_out[32]) {
+                                                  uint64_t proof_out[32]) try {
     if (!a || !b || !c) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     const uint64_t* src[3] = {a, b, c};
     return groth16_prove_multi<SuiteBn254>(ctx, keys, nkeys, w, 0u, src, len, r_mont, s_mont, proof_out);
-}
-extern "C" int32_t dvn_groth16_last_stats_json(const dvn_groth16_pk* pk, char* buf, size_t cap, size_t* needed) {
+} DVN_CATCH
+extern "C" int32_t dvn_groth16_last_stats_json(const dvn_groth16_pk* pk, char* buf, size_t cap, size_t* needed) try {
     if (!pk) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     return groth16_stats_json(pk, buf, cap, needed);
-}
+} DVN_CATCH
 
 // ---- curve-independent handles ------------------------------------------------------------------------------------
 // gnark's ecc.ID numbering of the prover package mirror: 1 BN254, 2 BLS12_377, 3 BLS12_381, 4 BW6_761
-extern "C" int32_t dvn_r1cs_curve(const dvn_r1cs* cs) { return !cs ? 0 : cs->suite == 0 ? 1 : cs->suite == 1 ? 2 : cs->suite == 3 ? 3 : cs->suite == 2 ? 4 : 0; }
-extern "C" int32_t dvn_r1cs_info(const dvn_r1cs* cs, uint32_t* n_wires, uint32_t* n_public, uint32_t* n_constraints) {
+extern "C" int32_t dvn_r1cs_curve(const dvn_r1cs* cs) try { return !cs ? 0 : cs->suite == 0 ? 1 : cs->suite == 1 ? 2 : cs->suite == 3 ? 3 : cs->suite == 2 ? 4 : 0; } DVN_CATCH
+extern "C" int32_t dvn_r1cs_info(const dvn_r1cs* cs, uint32_t* n_wires, uint32_t* n_public, uint32_t* n_constraints) try {
     if (!cs) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (n_wires) *n_wires = cs->n_wires;
     if (n_public) *n_public = cs->n_public;
     if (n_constraints) *n_constraints = cs->n_constraints;
     return DVN_OK;
-}
-extern "C" int32_t dvn_r1cs_witness(const dvn_r1cs* cs, uint64_t* out) {
+} DVN_CATCH
+extern "C" int32_t dvn_r1cs_witness(const dvn_r1cs* cs, uint64_t* out) try {
     if (!cs || !out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     memcpy(out, cs->witness.data(), cs->witness.size() * 4);
     return DVN_OK;
-}
+} DVN_CATCH
 extern "C" void dvn_r1cs_free(dvn_r1cs* cs) { delete cs; }
 
-extern "C" int32_t dvn_groth16_pk_free(dvn_ctx* ctx, dvn_groth16_pk* pk) {
+extern "C" int32_t dvn_groth16_pk_free(dvn_ctx* ctx, dvn_groth16_pk* pk) try {
     TRY(enter(ctx));
     if (!pk) return DVN_OK;
     if (pk->cached) return DVN_OK;             // resident in the artifact cache until dvn_shutdown
@@ -76,44 +76,44 @@ extern "C" int32_t dvn_groth16_pk_free(dvn_ctx* ctx, dvn_groth16_pk* pk) {
     if (pk->hk && pk->hk_free) pk->hk_free(pk->hk);
     delete pk;
     return DVN_OK;
-}
+} DVN_CATCH
 
-extern "C" int32_t dvn_groth16_pk_info(const dvn_groth16_pk* pk, uint32_t* log_n, uint64_t* sizes /* nA, nB, nK, nZ, nB2 */) {
+extern "C" int32_t dvn_groth16_pk_info(const dvn_groth16_pk* pk, uint32_t* log_n, uint64_t* sizes /* nA, nB, nK, nZ, nB2 */) try {
     if (!pk) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (log_n) *log_n = pk->log_n;
     if (sizes) { sizes[0] = pk->nA; sizes[1] = pk->nB; sizes[2] = pk->m - pk->k_first; sizes[3] = pk->n; sizes[4] = pk->nB; }
     return DVN_OK;
-}
+} DVN_CATCH
 
 // ---- gnark's own proving key, handed over once; then proofs from the solver's output -------------------------------------------
-extern "C" int32_t dvn_groth16_pk_import(dvn_ctx* ctx, const dvn_groth16_key_arrays* k, dvn_groth16_pk** out) { return groth16_pk_import_api<SuiteBn254>(ctx, k, out); }
+extern "C" int32_t dvn_groth16_pk_import(dvn_ctx* ctx, const dvn_groth16_key_arrays* k, dvn_groth16_pk** out) try { return groth16_pk_import_api<SuiteBn254>(ctx, k, out); } DVN_CATCH
 extern "C" int32_t dvn_groth16_prove_solved(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b,
-                                            const uint64_t* c, size_t len, const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32]) {
+                                            const uint64_t* c, size_t len, const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32]) try {
     return groth16_prove_solved<SuiteBn254>(ctx, pk, w, a, b, c, len, r_mont, s_mont, proof_out);
-}
-extern "C" int32_t dvn_groth16_pk_export_arrays(dvn_ctx* ctx, const dvn_groth16_pk* pk, int which, uint64_t* out, size_t cap_words, size_t* n_words) {
+} DVN_CATCH
+extern "C" int32_t dvn_groth16_pk_export_arrays(dvn_ctx* ctx, const dvn_groth16_pk* pk, int which, uint64_t* out, size_t cap_words, size_t* n_words) try {
     return groth16_pk_export_arrays<SuiteBn254>(ctx, pk, which, out, cap_words, n_words);
-}
+} DVN_CATCH
 
 // The verifying key Setup produced next to the proving key (groth16.Setup returns both, /root/reference/prover/setup.go:15-28),
 // as gnark affine Montgomery images: alpha (G1) | beta | gamma | delta (G2) | IC[n_public] (G1) | with a commitment: Pedersen
 // G | GSigmaNeg (G2).  n_words receives the total; out may be NULL to query it.
-extern "C" int32_t dvn_groth16_vk_export(const dvn_groth16_pk* pk, uint64_t* out, size_t cap_words, size_t* n_words) {
+extern "C" int32_t dvn_groth16_vk_export(const dvn_groth16_pk* pk, uint64_t* out, size_t cap_words, size_t* n_words) try {
     if (!pk || !n_words) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     *n_words = pk->vk_words.size();
     if (!out) return DVN_OK;
     if (cap_words < pk->vk_words.size()) return fail(DVN_ERR_INVALID_ARG, "buffer holds %zu words, the key needs %zu", cap_words, pk->vk_words.size());
     memcpy(out, pk->vk_words.data(), pk->vk_words.size() * 8);
     return DVN_OK;
-}
+} DVN_CATCH
 
-extern "C" int32_t dvn_groth16_last_ms(const dvn_groth16_pk* pk, float* ms_h, float* ms_msm, float* ms_total) {
+extern "C" int32_t dvn_groth16_last_ms(const dvn_groth16_pk* pk, float* ms_h, float* ms_msm, float* ms_total) try {
     if (!pk) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (ms_h) *ms_h = pk->ms_h;
     if (ms_msm) *ms_msm = pk->ms_msm;
     if (ms_total) *ms_total = pk->ms_total;
     return DVN_OK;
-}
+} DVN_CATCH
 
 
 // ------------------------------------------------------------------------------------------------------
@@ -131,7 +131,7 @@ static void fp_ext_to_be32(const u32* ext_words, uint8_t* out) {
     }
 }
 extern "C" int32_t dvn_groth16_proof_abi_encode(const uint64_t proof[32], const uint64_t commitment[8], const uint64_t commitment_pok[8],
-                                                uint8_t out[384]) {
+                                                uint8_t out[384]) try {
     if (!proof || !out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     const u32* p = (const u32*)proof;
     const u32* ar = p; const u32* bs = p + 16; const u32* krs = p + 48;
@@ -143,7 +143,7 @@ extern "C" int32_t dvn_groth16_proof_abi_encode(const uint64_t proof[32], const 
     if (commitment) { fp_ext_to_be32((const u32*)commitment, out + 256); fp_ext_to_be32((const u32*)commitment + 8, out + 288); }
     if (commitment_pok) { fp_ext_to_be32((const u32*)commitment_pok, out + 320); fp_ext_to_be32((const u32*)commitment_pok + 8, out + 352); }
     return DVN_OK;
-}
+} DVN_CATCH
 
 
 // ------------------------------------------------------------------------------------------------------
@@ -155,9 +155,9 @@ extern "C" int32_t dvn_groth16_proof_abi_encode(const uint64_t proof[32], const 
 // ------------------------------------------------------------------------------------------------------
 extern "C" int32_t dvn_pedersen_commit(dvn_ctx* ctx, const dvn_points* basis, const dvn_points* basis_exp_sigma,
                                        const uint64_t* values_mont, size_t n, uint32_t flags,
-                                       uint64_t commitment_out[8], uint64_t pok_out[8]) {
+                                       uint64_t commitment_out[8], uint64_t pok_out[8]) try {
     return pedersen_commit<SuiteBn254>(ctx, basis, basis_exp_sigma, values_mont, n, flags, commitment_out, pok_out);
-}
+} DVN_CATCH
 
 
 // ------------------------------------------------------------------------------------------------------
@@ -198,11 +198,11 @@ static void keccak256(const uint8_t* data, size_t len, uint8_t out[32]) {
     }
     for (int i = 0; i < 4; ++i) for (int k = 0; k < 8; ++k) out[8 * i + k] = (uint8_t)(st[i] >> (8 * k));
 }
-extern "C" int32_t dvn_keccak256(const uint8_t* data, size_t len, uint8_t out[32]) {
+extern "C" int32_t dvn_keccak256(const uint8_t* data, size_t len, uint8_t out[32]) try {
     if ((!data && len) || !out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     keccak256(data, len, out);
     return DVN_OK;
-}
+} DVN_CATCH
 static void fr_ext_to_be32(const u32* ext_words, uint8_t* out) {
     u32 t[8], c[8];
     memcpy(t, ext_words, 32);
@@ -213,28 +213,21 @@ static void fr_ext_to_be32(const u32* ext_words, uint8_t* out) {
     }
 }
 
-extern "C" int32_t dvn_r1cs_synthetic_committed(uint64_t seed, uint32_t n_constraints, uint32_t n_public, uint32_t n_committed, dvn_r1cs** out) {
+extern "C" int32_t dvn_r1cs_synthetic_committed(uint64_t seed, uint32_t n_constraints, uint32_t n_public, uint32_t n_committed, dvn_r1cs** out) try {
     if (!n_committed) return fail(DVN_ERR_INVALID_ARG, "n_committed must be positive");
     return r1cs_synthetic<SuiteBn254>(seed, n_constraints, n_public, out, n_committed, 2);
-}
+} DVN_CATCH
 
-// witness: the solver's assignment BEFORE the commitment is known (commitment wire and the constraints reading it are
-// placeholders; dvn_r1cs_witness of a committed instance returns exactly that).  commitment_out / pok_out: G1Affine images
-// (gnark Proof.Commitments[0], Proof.CommitmentPok); challenge_out: the commitment wire's value (Montgomery words).
-extern "C" int32_t dvn_groth16_prove_committed(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
-                                               const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32],
-                                               uint64_t commitment_out[8], uint64_t pok_out[8], uint64_t challenge_out[4]) {
+// The solver's side of a committed proof, up to the completed witness in pk->d_w (caller holds ctx->mu): upload, the commitment
+// hint (two MSMs over the committed wires, in flight together), the keccak challenge into its wire, the constraints that read
+// it.  Every rank / device of a shared proof runs this whole: the commitment bases are small next to the key's five sets, and
+// replicating them spares an exchange before the challenge (all ranks derive the same challenge from the same commitment).
+static int32_t committed_prepare(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
+                                 uint64_t commitment_out[8], uint64_t pok_out[8], uint64_t challenge_out[4]) {
     typedef SuiteBn254 SU;
     typedef FrCfg S;
     typedef dvn_host::HG1 H1;
     constexpr u32 EW = 8;
-    TRY(enter(ctx));
-    if (!pk || !witness || !r_mont || !s_mont || !proof_out || !commitment_out || !pok_out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
-    if (pk->suite != SU::SUITE) return fail(DVN_ERR_UNSUPPORTED, "committed proofs exist for BN254 keys only");
-    if (!pk->n_committed || pk->imported) return fail(DVN_ERR_INVALID_ARG, "the key has no commitment: use dvn_groth16_prove");
-    const HostKey<SU>& hk = *(const HostKey<SU>*)pk->hk;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    Blind<SU> bl(hk, r_mont, s_mont);
     hipStream_t st = ctx->stream;
     HIP_TRY(hipMemcpyAsync(pk->d_w, witness, pk->m * EW * 4, (flags & 1) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     // (1) the commitment hint: two MSMs over the committed wires, in flight together
@@ -273,8 +266,81 @@ extern "C" int32_t dvn_groth16_prove_committed(dvn_ctx* ctx, dvn_groth16_pk* pk,
                                            pk->d_w, (u32)(pk->n_constraints - pk->tail), (u32)pk->n_constraints);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));                 // cext lives on this stack frame
+    return DVN_OK;
+}
+static int32_t committed_key_check(const dvn_groth16_pk* pk) {
+    if (pk->suite != SuiteBn254::SUITE) return fail(DVN_ERR_UNSUPPORTED, "committed proofs exist for BN254 keys only");
+    if (!pk->n_committed || pk->imported) return fail(DVN_ERR_INVALID_ARG, "the key has no commitment: use dvn_groth16_prove");
+    return DVN_OK;
+}
+
+// witness: the solver's assignment BEFORE the commitment is known (commitment wire and the constraints reading it are
+// placeholders; dvn_r1cs_witness of a committed instance returns exactly that).  commitment_out / pok_out: G1Affine images
+// (gnark Proof.Commitments[0], Proof.CommitmentPok); challenge_out: the commitment wire's value (Montgomery words).
+extern "C" int32_t dvn_groth16_prove_committed(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
+                                               const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32],
+                                               uint64_t commitment_out[8], uint64_t pok_out[8], uint64_t challenge_out[4]) try {
+    typedef SuiteBn254 SU;
+    TRY(enter(ctx));
+    if (!pk || !witness || !r_mont || !s_mont || !proof_out || !commitment_out || !pok_out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    TRY(committed_key_check(pk));
+    const HostKey<SU>& hk = *(const HostKey<SU>*)pk->hk;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    Blind<SU> bl(hk, r_mont, s_mont);
+    TRY(committed_prepare(ctx, pk, witness, flags, commitment_out, pok_out, challenge_out));
     MsmResults<SU> R;
     TRY(groth16_device<SU>(ctx, pk, (const uint64_t*)pk->d_w, 1u | 2u, 0, 1, &R));
     groth16_assemble<SU>(hk, R, bl, proof_out);
     return DVN_OK;
-}
+} DVN_CATCH
+
+// The statetransition shape shared between the GPUs of a node (the proof the node serialises on,
+// /root/reference/sequencer/statetransition.go:80,248; one commitment: /root/reference/config/statetransition_vkey.sol:97-114).
+// Rank `rank` of `world`: the commitment hint, challenge and witness completion whole (replicated), then its entry share of the
+// five MSMs.  partial_out as dvn_groth16_prove_shard; every rank returns the same commitment, PoK and challenge;
+// dvn_groth16_prove_combine assembles the proof from the gathered partial results.
+extern "C" int32_t dvn_groth16_prove_committed_shard(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
+                                                     uint32_t rank, uint32_t world, uint64_t partial_out[72],
+                                                     uint64_t commitment_out[8], uint64_t pok_out[8], uint64_t challenge_out[4]) try {
+    typedef SuiteBn254 SU;
+    typedef SU::H1 H1;
+    typedef SU::H2 H2;
+    TRY(enter(ctx));
+    if (!pk || !witness || !partial_out || !commitment_out || !pok_out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    if (world < 1 || world > 64 || rank >= world) return fail(DVN_ERR_INVALID_ARG, "rank %u outside world %u", rank, world);
+    TRY(committed_key_check(pk));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(committed_prepare(ctx, pk, witness, flags, commitment_out, pok_out, challenge_out));
+    MsmResults<SU> R;
+    TRY(groth16_device<SU>(ctx, pk, (const uint64_t*)pk->d_w, 1u | 2u, rank, world, &R));
+    constexpr size_t J1 = PartialLayout<SU>::J1;
+    H1::write_jac(R.mA, partial_out); H1::write_jac(R.mB, partial_out + J1); H1::write_jac(R.mK, partial_out + 2 * J1);
+    H1::write_jac(R.mZ, partial_out + 3 * J1); H2::write_jac(R.mB2, partial_out + 4 * J1);
+    return DVN_OK;
+} DVN_CATCH
+// ... and over the devices of a multi-device context from one call: keys[i] = the committed key on dvn_ctx_device(ctx, i).
+extern "C" int32_t dvn_groth16_prove_committed_multi(dvn_ctx* ctx, dvn_groth16_pk* const* keys, uint32_t nkeys, const uint64_t* witness,
+                                                     const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32],
+                                                     uint64_t commitment_out[8], uint64_t pok_out[8], uint64_t challenge_out[4]) try {
+    if (!commitment_out || !pok_out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    if (keys) for (uint32_t i = 0; i < nkeys; ++i) if (keys[i]) TRY(committed_key_check(keys[i]));
+    // per device: prepare on its own copy of the key, then its share; device 0's commitment is the one handed back
+    std::vector<uint64_t> cm((size_t)nkeys * 20);
+    auto prepare = [&](dvn_ctx* ci, dvn_groth16_pk* pk, uint32_t i) -> int32_t {
+        return committed_prepare(ci, pk, witness, 0u, cm.data() + (size_t)i * 20, cm.data() + (size_t)i * 20 + 8, cm.data() + (size_t)i * 20 + 16);
+    };
+    TRY((groth16_prove_multi<SuiteBn254>(ctx, keys, nkeys, witness, 0u, nullptr, 0, r_mont, s_mont, proof_out, prepare)));
+    for (uint32_t i = 1; i < nkeys; ++i)
+        if (memcmp(cm.data(), cm.data() + (size_t)i * 20, 20 * 8)) return fail(DVN_ERR_DEVICE, "device %u derived a different commitment than device 0", i);
+    memcpy(commitment_out, cm.data(), 64); memcpy(pok_out, cm.data() + 8, 64);
+    if (challenge_out) memcpy(challenge_out, cm.data() + 16, 32);
+    return DVN_OK;
+} DVN_CATCH
+// uint64 words of the proof image the prover-package calls write for this key: Ar | Bs | Krs of the key's curve, followed by
+// Commitments[0] | CommitmentPok (two G1Affine images) when the key carries a BSB22 commitment
+extern "C" int32_t dvn_groth16_proof_words(const dvn_groth16_pk* pk, size_t* words) try {
+    if (!pk || !words) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    const size_t a1 = pk->g1_bytes / 8, a2 = pk->g2_bytes / 8;
+    *words = 2 * a1 + a2 + ((pk->n_committed && !pk->imported) ? 2 * a1 : 0);
+    return DVN_OK;
+} DVN_CATCH

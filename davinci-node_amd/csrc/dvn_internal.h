@@ -100,6 +100,9 @@ struct dvn_domain {
 };
 
 int32_t fail(int32_t code, const char* fmt, ...);
+// maps the exception in flight to an error code + message (dvn_core.hip); every extern "C" entry point ends in DVN_CATCH
+int32_t dvn_guard_fail() noexcept;
+#define DVN_CATCH catch (...) { return dvn_guard_fail(); }
 
 // rocprofv3 / roctracer ranges around the stages of a proof (H2D, gathers, each MSM, computeH and its transforms, collect):
 // resolved with dlopen at first use and only when DVN_ROCTX=1, so the library has no link-time dependency on a profiler

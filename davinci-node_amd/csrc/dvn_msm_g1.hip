@@ -3,21 +3,21 @@
 
 int32_t dvn_internal_points_download_g2(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, uint64_t* xy);   // dvn_msm_g2.hip
 
-extern "C" int32_t dvn_points_upload_g1(dvn_ctx* ctx, const uint64_t* xy, size_t n, dvn_points** out) { return points_upload<G1>(ctx, xy, n, 1, out); }
+extern "C" int32_t dvn_points_upload_g1(dvn_ctx* ctx, const uint64_t* xy, size_t n, dvn_points** out) try { return points_upload<G1>(ctx, xy, n, 1, out); } DVN_CATCH
 
-extern "C" int32_t dvn_points_synthetic_g1(dvn_ctx* ctx, uint64_t seed, size_t n, dvn_points** out) { return points_synthetic<G1>(ctx, seed, n, 1, g1_generator(), out); }
+extern "C" int32_t dvn_points_synthetic_g1(dvn_ctx* ctx, uint64_t seed, size_t n, dvn_points** out) try { return points_synthetic<G1>(ctx, seed, n, 1, g1_generator(), out); } DVN_CATCH
 
-extern "C" int32_t dvn_msm_g1_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags, int32_t* ticket) {
+extern "C" int32_t dvn_msm_g1_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags, int32_t* ticket) try {
     return msm_submit_api<G1>(ctx, pts, 1, off, n, scalars, flags, ticket);
-}
-extern "C" int32_t dvn_msm_g1_collect(dvn_ctx* ctx, int32_t ticket, uint64_t out_jac[12]) { return msm_collect_api<G1>(ctx, 1, ticket, out_jac); }
-extern "C" int32_t dvn_msm_g1(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags, uint64_t out_jac[12]) {
+} DVN_CATCH
+extern "C" int32_t dvn_msm_g1_collect(dvn_ctx* ctx, int32_t ticket, uint64_t out_jac[12]) try { return msm_collect_api<G1>(ctx, 1, ticket, out_jac); } DVN_CATCH
+extern "C" int32_t dvn_msm_g1(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags, uint64_t out_jac[12]) try {
     return msm_full<G1>(ctx, pts, 1, off, n, scalars, flags, out_jac);
-}
+} DVN_CATCH
 
 // ---- the entry point that allocates nothing ----------------------------------------------------------------------------
 // dvn_msm_g1 keeps its sort / bucket / partial-sum arrays in a grow-only hipMalloc'ed workspace.  Callers that cannot allocate
-// (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc) get the same MSM over a FIXED scratch
+// (tight serving loops, harnesses that forbid hipMalloc, code that must not disturb the allocator) get the same MSM over a FIXED scratch
 // buffer: a file-scope device array of DVN_MSM_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the
 // process ends.  Its device address differs per GPU: it is resolved once per context (= per device) at dvn_init, with that
 // device current, and only that pointer -- never the array's name -- is handed to kernels and fills.
@@ -34,15 +34,21 @@ int32_t dvn_internal_static_scratch_init(dvn_ctx* ctx) {
 // Same result as dvn_msm_g1 (same kernels), n <= DVN_MSM_STATIC_MAX_N, scalars already in device memory.  No hipMalloc / hipFree:
 // scratch comes from the static array, clears are fill kernels, the result leaves through the lane's pinned buffer of dvn_init.
 // All calls on one GPU share that GPU's array (it keeps the previous call's contents; everything that must start at zero is
-// cleared per call): calls that overlap on one GPU -- two contexts on the same device -- race.
+// cleared per call).  Calls through this library are serialised per device -- a process-wide mutex per ordinal, held from
+// submit to collect, because dvn_init may put several contexts on one GPU -- so they cannot corrupt each other; anything ELSE
+// that touches the array at the same time (another process image of the library on the same GPU has its own copy) would race.
+// The call synchronises its stream and finishes on the host: it is not capturable into a HIP graph.
+static std::mutex static_scratch_mu[64];
 extern "C" int32_t dvn_msm_g1_static(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* d_scalars_mont,
-                                     uint32_t flags, uint64_t out_jac[12]) {
+                                     uint32_t flags, uint64_t out_jac[12]) try {
     TRY(enter(ctx));
     if (!pts || !out_jac || (!d_scalars_mont && n)) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (pts->curve != 1 || pts->suite != 0) return fail(DVN_ERR_INVALID_ARG, "point set is not BN254 G1");
     if (!(flags & DVN_MSM_SCALARS_ON_DEVICE)) return fail(DVN_ERR_INVALID_ARG, "dvn_msm_g1_static takes device scalars only (DVN_MSM_SCALARS_ON_DEVICE): a host copy could allocate staging memory");
     if (n > DVN_MSM_STATIC_MAX_N) return fail(DVN_ERR_INVALID_ARG, "n = %zu exceeds DVN_MSM_STATIC_MAX_N = %u, the most the %zu-byte static scratch buffer serves", n, (unsigned)DVN_MSM_STATIC_MAX_N, DVN_MSM_STATIC_SCRATCH_BYTES);
     typedef FastHost<G1>::G HG;
+    if (ctx->device < 0 || ctx->device >= 64) return fail(DVN_ERR_INVALID_ARG, "device ordinal %d out of range", ctx->device);
+    std::lock_guard<std::mutex> dev_lk(static_scratch_mu[ctx->device]);      // sibling contexts on this GPU share the scratch array
     std::lock_guard<std::mutex> lk(ctx->mu);
     MsmLane* L = nullptr;
     TRY(msm_submit<G1>(ctx, pts, off, n, d_scalars_mont, flags, &L, /*static_scratch=*/true));
@@ -50,14 +56,14 @@ extern "C" int32_t dvn_msm_g1_static(dvn_ctx* ctx, const dvn_points* pts, size_t
     TRY(msm_collect<G1>(ctx, *L, &r));
     HG::write_jac(r, out_jac);
     return DVN_OK;
-}
+} DVN_CATCH
 
 // B MultiExps over ONE point set in one pass of the pipeline: every (vector, window) pair is a virtual window of the same
 // sorted entry list (msm_driver.h msm_windows_staged, batched mode), the window sums are combined per vector on the device.
 // For many commitments over one basis (a PLONK prover's wire / quotient polynomials over one SRS, several BSB22 commitments
 // over one key): B small MSMs cost one launch sequence instead of B.  scalars: batch x n images, vector b at [b*n, (b+1)*n).
 extern "C" int32_t dvn_msm_g1_batched(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t batch,
-                                      uint32_t flags, uint64_t* out_jac /* batch x 12 */) {
+                                      uint32_t flags, uint64_t* out_jac /* batch x 12 */) try {
     TRY(enter(ctx));
     if (!pts || !out_jac || (!scalars && n && batch)) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (pts->curve != 1 || pts->suite != 0) return fail(DVN_ERR_INVALID_ARG, "point set is not BN254 G1");
@@ -93,17 +99,17 @@ extern "C" int32_t dvn_msm_g1_batched(dvn_ctx* ctx, const dvn_points* pts, size_
     TRY(rc);
     for (uint32_t b = 0; b < batch; ++b) HG::write_jac(HG::load_device(h.data() + (size_t)b * G1::XW), out_jac + (size_t)b * 12);
     return DVN_OK;
-}
+} DVN_CATCH
 
 // (window_bits, nwin, combine_bits) the library will use for an n-scalar MSM over this point set.  Expanded sets
 // have pts-specific windows and combine_bits = 0: partial results of window ranges simply add up.
-extern "C" int32_t dvn_msm_plan_points(const dvn_points* pts, size_t n, uint32_t* window_bits, uint32_t* nwin, uint32_t* combine_bits) {
+extern "C" int32_t dvn_msm_plan_points(const dvn_points* pts, size_t n, uint32_t* window_bits, uint32_t* nwin, uint32_t* combine_bits) try {
     if (!pts || !window_bits || !nwin || !combine_bits) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (use_expanded(pts, n)) { *window_bits = pts->expand_c; *nwin = pts->nexp; *combine_bits = 0; return DVN_OK; }
     msm_plan(n, window_bits, nwin);
     *combine_bits = *window_bits;
     return DVN_OK;
-}
+} DVN_CATCH
 // window-sharded MSM, asynchronous halves: submit queues windows [win_lo, win_hi) on a free lane, collect exports the
 // per-window sums (external-Montgomery X, Y, ZZ, ZZZ; infinity = all zero).  Expanded sets put the partial result in slot 0.
 static int32_t windows_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
@@ -153,7 +159,7 @@ static int32_t windows_collect(dvn_ctx* ctx, MsmLane& L, uint64_t* window_sums) 
     return DVN_OK;
 }
 extern "C" int32_t dvn_msm_g1_windows_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
-                                             uint32_t win_lo, uint32_t win_hi, int32_t* ticket) {
+                                             uint32_t win_lo, uint32_t win_hi, int32_t* ticket) try {
     TRY(enter(ctx));
     if (!ticket) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -161,25 +167,25 @@ extern "C" int32_t dvn_msm_g1_windows_submit(dvn_ctx* ctx, const dvn_points* pts
     TRY(windows_submit(ctx, pts, off, n, scalars, flags, win_lo, win_hi, &L));
     *ticket = (int32_t)(L - ctx->lane) + 1;
     return DVN_OK;
-}
-extern "C" int32_t dvn_msm_g1_windows_collect(dvn_ctx* ctx, int32_t ticket, uint64_t* window_sums) {
+} DVN_CATCH
+extern "C" int32_t dvn_msm_g1_windows_collect(dvn_ctx* ctx, int32_t ticket, uint64_t* window_sums) try {
     TRY(enter(ctx));
     if (!window_sums || ticket < 1 || ticket > DVN_LANES) return fail(DVN_ERR_INVALID_ARG, "bad ticket");
     std::lock_guard<std::mutex> lk(ctx->mu);
     MsmLane& L = ctx->lane[ticket - 1];
     if (!L.busy || L.curve != 1 || L.suite != 0) return fail(DVN_ERR_INVALID_ARG, "ticket %d is not an outstanding window-sharded BN254 G1 MSM", ticket);
     return windows_collect(ctx, L, window_sums);
-}
+} DVN_CATCH
 extern "C" int32_t dvn_msm_g1_windows(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
-                                      uint32_t win_lo, uint32_t win_hi, uint64_t* window_sums) {
+                                      uint32_t win_lo, uint32_t win_hi, uint64_t* window_sums) try {
     TRY(enter(ctx));
     if (!window_sums) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     std::lock_guard<std::mutex> lk(ctx->mu);
     MsmLane* L = nullptr;
     TRY(windows_submit(ctx, pts, off, n, scalars, flags, win_lo, win_hi, &L));
     return windows_collect(ctx, *L, window_sums);
-}
-extern "C" int32_t dvn_msm_combine_g1(dvn_ctx* ctx, const uint64_t* window_sums, uint32_t nwin, uint32_t window_bits, uint64_t out_jac[12]) {
+} DVN_CATCH
+extern "C" int32_t dvn_msm_combine_g1(dvn_ctx* ctx, const uint64_t* window_sums, uint32_t nwin, uint32_t window_bits, uint64_t out_jac[12]) try {
     (void)ctx;   /* pure host computation: ctx may be NULL (CPU-side tests of the sharded path) */
     if (!window_sums || !out_jac) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (window_bits > 24 || nwin == 0 || nwin > 64) return fail(DVN_ERR_INVALID_ARG, "bad window layout");   /* window_bits 0 = plain sum */
@@ -194,7 +200,7 @@ extern "C" int32_t dvn_msm_combine_g1(dvn_ctx* ctx, const uint64_t* window_sums,
     }
     dvn_host::HG1::write_jac(dvn_host::HG1::horner(sums.data(), nwin, window_bits), out_jac);
     return DVN_OK;
-}
+} DVN_CATCH
 
 // ---- one MSM shared between the GPUs of a node by entry count ---------------------------------------------------------------
 // Rank `rank` of `world` computes ITS SHARE of sum s_i P_i and returns it as a G1Jac image; the shares of all ranks add up to
@@ -203,7 +209,7 @@ extern "C" int32_t dvn_msm_combine_g1(dvn_ctx* ctx, const uint64_t* window_sums,
 // ranks is one all-gather of 96 bytes per rank (RCCL has no elliptic-curve reduction operator; the sum runs on the host).
 // Scalars must already be in device memory.
 extern "C" int32_t dvn_msm_g1_share_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* d_scalars_mont,
-                                           uint32_t flags, uint32_t rank, uint32_t world, int32_t* ticket) {
+                                           uint32_t flags, uint32_t rank, uint32_t world, int32_t* ticket) try {
     TRY(enter(ctx));
     if (!pts || !ticket || (!d_scalars_mont && n)) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (pts->curve != 1 || pts->suite != 0) return fail(DVN_ERR_INVALID_ARG, "point set is not BN254 G1");
@@ -213,9 +219,9 @@ extern "C" int32_t dvn_msm_g1_share_submit(dvn_ctx* ctx, const dvn_points* pts, 
     TRY(msm_share_submit<G1>(ctx, pts, off, n, (const u32*)d_scalars_mont, rank, world, &L));
     *ticket = (int32_t)(L - ctx->lane) + 1;
     return DVN_OK;
-}
-extern "C" int32_t dvn_msm_g1_share_collect(dvn_ctx* ctx, int32_t ticket, uint64_t partial_jac[12]) { return msm_collect_api<G1>(ctx, 1, ticket, partial_jac); }
-extern "C" int32_t dvn_msm_g1_sum(const uint64_t* jacs, uint32_t count, uint64_t out_jac[12]) {
+} DVN_CATCH
+extern "C" int32_t dvn_msm_g1_share_collect(dvn_ctx* ctx, int32_t ticket, uint64_t partial_jac[12]) try { return msm_collect_api<G1>(ctx, 1, ticket, partial_jac); } DVN_CATCH
+extern "C" int32_t dvn_msm_g1_sum(const uint64_t* jacs, uint32_t count, uint64_t out_jac[12]) try {
     typedef dvn_host::HG1 HG;
     if ((!jacs && count) || !out_jac) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     HG::X acc = HG::infinity();
@@ -224,17 +230,19 @@ extern "C" int32_t dvn_msm_g1_sum(const uint64_t* jacs, uint32_t count, uint64_t
         bool z = true;
         for (int i = 0; i < 8; ++i) z = z && w[16 + i] == 0;                    // Z == 0: infinity
         if (z) continue;
+        static const u64 ONE_MONT[4] = {0xd35d438dc58f0d9dULL, 0x0a78eb28f5c70b3dULL, 0x666ea36f7879462cULL, 0x0e0a77c19a07df2fULL};   // 2^256 mod p
+        if (memcmp(w + 16, ONE_MONT, 32) != 0) return fail(DVN_ERR_INVALID_ARG, "jacs[%u]: Z is neither 0 nor 1 -- this sum takes the normalised images the library emits (Z in {0, 1})", k);
         u32 img[G1::AW];
         G1::store_affine_internal(G1::affine_from_ext(w), img);                 // Z = 1 images (what the library emits)
         acc = HG::add(acc, HG::load_device_affine(img));
     }
     HG::write_jac(acc, out_jac);
     return DVN_OK;
-}
+} DVN_CATCH
 
 extern "C" size_t dvn_points_len(const dvn_points* pts) { return pts ? pts->n : 0; }
 
-extern "C" int32_t dvn_points_free(dvn_ctx* ctx, dvn_points* pts) {
+extern "C" int32_t dvn_points_free(dvn_ctx* ctx, dvn_points* pts) try {
     TRY(enter(ctx));
     if (!pts) return DVN_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -242,31 +250,31 @@ extern "C" int32_t dvn_points_free(dvn_ctx* ctx, dvn_points* pts) {
     if (pts->d) HIP_TRY(hipFree(pts->d));
     delete pts;
     return DVN_OK;
-}
+} DVN_CATCH
 
-extern "C" int32_t dvn_points_download(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, uint64_t* xy) {
+extern "C" int32_t dvn_points_download(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, uint64_t* xy) try {
     TRY(enter(ctx));
     if (!pts || (!xy && n)) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (pts->suite != 0) return fail(DVN_ERR_INVALID_ARG, "point set is not a BN254 set (use the download call of its curve)");
     if (off > pts->n || n > pts->n - off) return fail(DVN_ERR_INVALID_ARG, "range [%zu, %zu) outside point set of %zu", off, off + n, pts->n);
     std::lock_guard<std::mutex> lk(ctx->mu);
     return pts->curve == 1 ? points_download<G1>(ctx, pts, off, n, xy) : dvn_internal_points_download_g2(ctx, pts, off, n, xy);
-}
+} DVN_CATCH
 
 int32_t dvn_internal_points_set_expanded_g2(dvn_ctx* ctx, dvn_points* pts, u32 c);   // dvn_msm_g2.hip
-extern "C" int32_t dvn_points_set_expanded(dvn_ctx* ctx, dvn_points* pts, uint32_t window_bits) {
+extern "C" int32_t dvn_points_set_expanded(dvn_ctx* ctx, dvn_points* pts, uint32_t window_bits) try {
     TRY(enter(ctx));
     if (!pts) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     std::lock_guard<std::mutex> lk(ctx->mu);
     return pts->curve == 1 ? points_set_expanded<G1>(ctx, pts, window_bits) : dvn_internal_points_set_expanded_g2(ctx, pts, window_bits);
-}
-extern "C" int32_t dvn_msm_plan(size_t n, uint32_t* window_bits, uint32_t* nwin) {
+} DVN_CATCH
+extern "C" int32_t dvn_msm_plan(size_t n, uint32_t* window_bits, uint32_t* nwin) try {
     if (!window_bits || !nwin) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     msm_plan(n, window_bits, nwin);
     return DVN_OK;
-}
+} DVN_CATCH
 
-extern "C" int32_t dvn_scalars_synthetic(dvn_ctx* ctx, uint64_t seed, int kind, size_t n, void* d_out) {
+extern "C" int32_t dvn_scalars_synthetic(dvn_ctx* ctx, uint64_t seed, int kind, size_t n, void* d_out) try {
     TRY(enter(ctx));
     if (!d_out && n) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (kind != 0 && kind != 1) return fail(DVN_ERR_INVALID_ARG, "kind must be 0 (uniform) or 1 (witness-like)");
@@ -276,7 +284,7 @@ extern "C" int32_t dvn_scalars_synthetic(dvn_ctx* ctx, uint64_t seed, int kind, 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return DVN_OK;
-}
+} DVN_CATCH
 
 int32_t dvn_internal_msm_g1_dev(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, dvn_host::HG1::X* out) {
     if (pts->curve != 1) return fail(DVN_ERR_INVALID_ARG, "point set is not G1");

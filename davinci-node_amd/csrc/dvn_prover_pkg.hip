@@ -60,6 +60,11 @@ int32_t callGPUProver(const Request* q) {
     switch (q->curve) {
         case BN254:
             if (!q->pk) return fail(DVN_ERR_INVALID_ARG, "proving key type mismatch for BN254: expected a device-resident dvn_groth16_pk, got NULL");
+            {   // the statetransition key carries one BSB22 commitment: its proof image continues with Commitments[0] | CommitmentPok
+                size_t words = 0;
+                if (dvn_groth16_proof_words(q->pk, &words) == DVN_OK && words == 48)
+                    return dvn_groth16_prove_committed(q->ctx, q->pk, q->witness, 0, q->r, q->s, q->proof, q->proof + 32, q->proof + 40, nullptr);
+            }
             return dvn_groth16_prove(q->ctx, q->pk, q->witness, 0, q->r, q->s, q->proof);
         case BLS12_377:          // the reference also sets PinToGPU here (prover_gpu.go:41): keys are always device-resident in this library
             if (!q->pk) return fail(DVN_ERR_INVALID_ARG, "proving key type mismatch for BLS12_377: expected a device-resident dvn_groth16_pk, got NULL");
@@ -118,28 +123,28 @@ int32_t Setup(dvn_ctx* ctx, const dvn_r1cs* ccs, uint64_t seed, dvn_groth16_pk**
 }  // namespace prover
 
 // ---- C-ABI of the package mirror -----------------------------------------------------------------------------
-extern "C" int32_t dvn_prover_use_gpu(void) { return prover::UseGPUProver.load() ? 1 : 0; }
+extern "C" int32_t dvn_prover_use_gpu(void) try { return prover::UseGPUProver.load() ? 1 : 0; } DVN_CATCH
 extern "C" void dvn_prover_set_use_gpu(int32_t on) { prover::UseGPUProver.store(on != 0); }
 extern "C" void dvn_prover_reload_env(void) { prover::init_from_env(); }
 extern "C" void dvn_prover_set_prover(prover::ProverFunc p, void* user) { prover::SetProver(p, user); }
 extern "C" void dvn_prover_set_cpu_backend(prover::CpuBackend b, void* user) { prover::SetCpuBackend(b, user); }
-extern "C" int32_t dvn_prover_last_backend(void) { return prover::last_backend; }
+extern "C" int32_t dvn_prover_last_backend(void) try { return prover::last_backend; } DVN_CATCH
 extern "C" int32_t dvn_prover_prove(dvn_ctx* ctx, int32_t curve, const dvn_r1cs* ccs, dvn_groth16_pk* pk, const uint64_t* witness,
-                                    const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out) {
+                                    const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out) try {
     prover::Request q{curve, ctx, ccs, pk, witness, r_mont, s_mont, proof_out};
     return prover::Prove(&q);
-}
+} DVN_CATCH
 extern "C" int32_t dvn_prover_gpu_prover(dvn_ctx* ctx, int32_t curve, const dvn_r1cs* ccs, dvn_groth16_pk* pk, const uint64_t* witness,
-                                         const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out) {
+                                         const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out) try {
     // a process that holds no device context is this library's "CPU build": the reference's exported stubs there panic with this
     // text whatever their arguments (prover/prover_cpu.go:41-44, 61-64; pinned by prover/prover_cpu_test.go:7-25)
     if (!ctx) { prover::note_backend(1); return fail(DVN_ERR_UNSUPPORTED, "GPU prover not supported in this build"); }
     prover::Request q{curve, ctx, ccs, pk, witness, r_mont, s_mont, proof_out};
     return prover::GPUProver(&q);
-}
+} DVN_CATCH
 extern "C" int32_t dvn_prover_cpu_prover(dvn_ctx* ctx, int32_t curve, const dvn_r1cs* ccs, dvn_groth16_pk* pk, const uint64_t* witness,
-                                         const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out) {
+                                         const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out) try {
     prover::Request q{curve, ctx, ccs, pk, witness, r_mont, s_mont, proof_out};
     return prover::CPUProver(&q);
-}
-extern "C" int32_t dvn_prover_setup(dvn_ctx* ctx, const dvn_r1cs* ccs, uint64_t seed, dvn_groth16_pk** pk) { return prover::Setup(ctx, ccs, seed, pk); }
+} DVN_CATCH
+extern "C" int32_t dvn_prover_setup(dvn_ctx* ctx, const dvn_r1cs* ccs, uint64_t seed, dvn_groth16_pk** pk) try { return prover::Setup(ctx, ccs, seed, pk); } DVN_CATCH

@@ -864,9 +864,16 @@ template <class SU> static int32_t groth16_prove_combine(const dvn_groth16_pk* p
 // are added on the host (five group additions per device), then blinded and assembled as usual.  No collective is involved:
 // one process sees all partial results, and the whole exchange is 5 points per device.  The statetransition proof is the
 // node's serialisation point (/root/reference/sequencer/statetransition.go:80): this is the call that shortens it.
-template <class SU> static int32_t groth16_prove_multi(dvn_ctx* ctx, dvn_groth16_pk* const* keys, uint32_t nkeys, const uint64_t* witness, uint32_t flags,
+// prepare (optional): run on every device, with that device's context locked, before its share -- the solver-side steps of a
+// committed proof; when given, the share reads the completed witness the hook left in the key's d_w.
+struct NoPrepare { int32_t operator()(dvn_ctx*, dvn_groth16_pk*, uint32_t) const { return DVN_OK; } static constexpr bool active = false; };
+template <class T> struct PrepareActive { static constexpr bool value = true; };
+template <> struct PrepareActive<NoPrepare> { static constexpr bool value = false; };
+template <class SU, class Prepare = NoPrepare>
+static int32_t groth16_prove_multi(dvn_ctx* ctx, dvn_groth16_pk* const* keys, uint32_t nkeys, const uint64_t* witness, uint32_t flags,
                                                        const uint64_t* const* abc_host, size_t abc_len,
-                                                       const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out) {
+                                                       const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out, Prepare prepare = Prepare()) {
+    constexpr bool prepared = PrepareActive<Prepare>::value;
     typedef typename SU::H1 H1;
     typedef typename SU::H2 H2;
     if (!ctx) return fail(DVN_ERR_INVALID_ARG, "ctx is NULL");
@@ -882,7 +889,7 @@ template <class SU> static int32_t groth16_prove_multi(dvn_ctx* ctx, dvn_groth16
         if (pk->device != ci->device) return fail(DVN_ERR_INVALID_ARG, "keys[%u] lives on device %d, the context's device %u is %d", i, pk->device, i, ci->device);
         if (pk->m != keys[0]->m || pk->n != keys[0]->n) return fail(DVN_ERR_INVALID_ARG, "keys[%u] is not the same key as keys[0]", i);
         if (!abc_host && pk->imported) return fail(DVN_ERR_INVALID_ARG, "imported key: prove from the solver's output (prove_solved_multi)");
-        if (pk->n_committed && !pk->imported) return fail(DVN_ERR_INVALID_ARG, "the key carries a BSB22 commitment: not supported by the multi-device prover");
+        if (pk->n_committed && !pk->imported && !prepared) return fail(DVN_ERR_INVALID_ARG, "the key carries a BSB22 commitment: use dvn_groth16_prove_committed_multi");
         if (abc_host && abc_len > pk->n) return fail(DVN_ERR_INVALID_ARG, "len = %zu exceeds the domain size %zu", abc_len, pk->n);
     }
     const HostKey<SU>& hk = *(const HostKey<SU>*)keys[0]->hk;
@@ -891,6 +898,7 @@ template <class SU> static int32_t groth16_prove_multi(dvn_ctx* ctx, dvn_groth16
     std::vector<int32_t> rcs(ndev, DVN_OK);
     std::vector<std::string> errs(ndev);
     std::vector<std::thread> threads;
+    threads.reserve(ndev);                                      // no reallocation (and no throw) once a thread runs
     bool spawn_failed = false;
     for (uint32_t i = 0; i < ndev && !spawn_failed; ++i) {
         try {
@@ -900,7 +908,10 @@ template <class SU> static int32_t groth16_prove_multi(dvn_ctx* ctx, dvn_groth16
             if (rc == DVN_OK) {
                 std::lock_guard<std::mutex> lk(ci->mu);
                 RoctxRange rr("dvn:device_share");
-                rc = groth16_device<SU>(ci, keys[i], witness, 0u, i, ndev, &parts[i], abc_host, abc_len);
+                if constexpr (prepared) {
+                    rc = prepare(ci, keys[i], i);
+                    if (rc == DVN_OK) rc = groth16_device<SU>(ci, keys[i], (const uint64_t*)keys[i]->d_w, 1u | 2u, i, ndev, &parts[i]);
+                } else rc = groth16_device<SU>(ci, keys[i], witness, 0u, i, ndev, &parts[i], abc_host, abc_len);
             }
             rcs[i] = rc;
             if (rc != DVN_OK) errs[i] = tl_error;

@@ -306,16 +306,16 @@ static void kzg_setup_destroy(dvn_kzg_setup* s) {            // no locking, no c
     for (void* b : bufs) if (b) (void)hipFree(b);
     delete s;
 }
-extern "C" int32_t dvn_kzg_setup_free(dvn_ctx* ctx, dvn_kzg_setup* s) {
+extern "C" int32_t dvn_kzg_setup_free(dvn_ctx* ctx, dvn_kzg_setup* s) try {
     TRY(enter(ctx));
     if (!s) return DVN_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
     (void)hipDeviceSynchronize();
     kzg_setup_destroy(s);
     return DVN_OK;
-}
+} DVN_CATCH
 
-extern "C" int32_t dvn_kzg_setup_load(dvn_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t* g1_monomial, dvn_kzg_setup** out) {
+extern "C" int32_t dvn_kzg_setup_load(dvn_ctx* ctx, const uint8_t* g1_lagrange, const uint8_t* g1_monomial, dvn_kzg_setup** out) try {
     TRY(enter(ctx));
     if (!g1_lagrange || !out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     dvn_kzg_setup* s = new (std::nothrow) dvn_kzg_setup();
@@ -344,7 +344,7 @@ extern "C" int32_t dvn_kzg_setup_load(dvn_ctx* ctx, const uint8_t* g1_lagrange, 
         (g1_monomial && (rc = msm_row_table_create<G1_381>(ctx, s->monomial, kzg::QN, s->c_cells, &s->rows_cells, &s->tab_monomial)))) { kzg_setup_destroy(s); return rc; }
     *out = s;
     return DVN_OK;
-}
+} DVN_CATCH
 
 // blob bytes -> device scalar images in s->d_f (caller holds ctx->mu)
 static int32_t kzg_load_blob(dvn_ctx* ctx, const dvn_kzg_setup* s, const uint8_t* blob) {
@@ -403,13 +403,13 @@ static int32_t kzg_commit(dvn_ctx* ctx, const dvn_kzg_setup* s, const dvn_points
     return rc;
 }
 
-extern "C" int32_t dvn_kzg_blob_to_commitment(dvn_ctx* ctx, const dvn_kzg_setup* s, const uint8_t* blob, uint8_t out[48]) {
+extern "C" int32_t dvn_kzg_blob_to_commitment(dvn_ctx* ctx, const dvn_kzg_setup* s, const uint8_t* blob, uint8_t out[48]) try {
     TRY(enter(ctx));
     if (!s || !blob || !out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     std::lock_guard<std::mutex> lk(ctx->mu);
     TRY(kzg_load_blob(ctx, s, blob));
     return kzg_commit(ctx, s, s->lagrange_brp, s->tab_lagrange, s->c_single, kzg::N, s->d_f, 1, out);
-}
+} DVN_CATCH
 
 static int32_t kzg_scalar_from_be(const uint8_t z_be[32], u32 zw[8]) {
     static const u32 R381[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
@@ -432,7 +432,7 @@ static int32_t kzg_quotient(dvn_ctx* ctx, const dvn_kzg_setup* s, const u32 zw[8
     return DVN_OK;
 }
 
-extern "C" int32_t dvn_kzg_evaluate_barycentric(dvn_ctx* ctx, const dvn_kzg_setup* s, const uint8_t* blob, const uint8_t z[32], uint8_t y[32]) {
+extern "C" int32_t dvn_kzg_evaluate_barycentric(dvn_ctx* ctx, const dvn_kzg_setup* s, const uint8_t* blob, const uint8_t z[32], uint8_t y[32]) try {
     TRY(enter(ctx));
     if (!s || !blob || !z || !y) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     u32 zw[8];
@@ -440,9 +440,9 @@ extern "C" int32_t dvn_kzg_evaluate_barycentric(dvn_ctx* ctx, const dvn_kzg_setu
     std::lock_guard<std::mutex> lk(ctx->mu);
     TRY(kzg_load_blob(ctx, s, blob));
     return kzg_quotient(ctx, s, zw, y);
-}
+} DVN_CATCH
 
-extern "C" int32_t dvn_kzg_compute_proof(dvn_ctx* ctx, const dvn_kzg_setup* s, const uint8_t* blob, const uint8_t z[32], uint8_t proof[48], uint8_t y[32]) {
+extern "C" int32_t dvn_kzg_compute_proof(dvn_ctx* ctx, const dvn_kzg_setup* s, const uint8_t* blob, const uint8_t z[32], uint8_t proof[48], uint8_t y[32]) try {
     TRY(enter(ctx));
     if (!s || !blob || !z || !proof || !y) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     u32 zw[8];
@@ -451,7 +451,7 @@ extern "C" int32_t dvn_kzg_compute_proof(dvn_ctx* ctx, const dvn_kzg_setup* s, c
     TRY(kzg_load_blob(ctx, s, blob));
     TRY(kzg_quotient(ctx, s, zw, y));
     return kzg_commit(ctx, s, s->lagrange_brp, s->tab_lagrange, s->c_single, kzg::N, s->d_q, 1, proof);
-}
+} DVN_CATCH
 
 // ---- SHA-256 (host): the Fiat-Shamir challenge of compute_blob_kzg_proof --------------------------------------------------
 static void kzg_sha256(const uint8_t* data, size_t len, uint8_t out[32]) {
@@ -484,16 +484,16 @@ static void kzg_sha256(const uint8_t* data, size_t len, uint8_t out[32]) {
     }
     for (int i = 0; i < 8; ++i) { out[4 * i] = (uint8_t)(h[i] >> 24); out[4 * i + 1] = (uint8_t)(h[i] >> 16); out[4 * i + 2] = (uint8_t)(h[i] >> 8); out[4 * i + 3] = (uint8_t)h[i]; }
 }
-extern "C" int32_t dvn_sha256(const uint8_t* data, size_t len, uint8_t out[32]) {
+extern "C" int32_t dvn_sha256(const uint8_t* data, size_t len, uint8_t out[32]) try {
     if ((!data && len) || !out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     kzg_sha256(data, len, out);
     return DVN_OK;
-}
+} DVN_CATCH
 
 // Blob.ComputeBlobProof (/root/reference/types/blobs.go:108-117, gethkzg.ComputeBlobProof): EIP-4844 compute_blob_kzg_proof --
 // the opening proof at the Fiat-Shamir point z = sha256("FSBLOBVERIFY_V1_" || uint128_be(4096) || blob || commitment) mod r
 // (compute_challenge).  Like the reference's method it does not check that the commitment belongs to the blob.
-extern "C" int32_t dvn_kzg_compute_blob_proof(dvn_ctx* ctx, const dvn_kzg_setup* s, const uint8_t* blob, const uint8_t commitment[48], uint8_t proof[48]) {
+extern "C" int32_t dvn_kzg_compute_blob_proof(dvn_ctx* ctx, const dvn_kzg_setup* s, const uint8_t* blob, const uint8_t commitment[48], uint8_t proof[48]) try {
     TRY(enter(ctx));
     if (!s || !blob || !commitment || !proof) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     std::vector<uint8_t> buf(32 + (size_t)kzg::N * 32 + 48, 0);
@@ -511,9 +511,9 @@ extern "C" int32_t dvn_kzg_compute_blob_proof(dvn_ctx* ctx, const dvn_kzg_setup*
     TRY(kzg_load_blob(ctx, s, blob));
     TRY(kzg_quotient(ctx, s, zw, y));
     return kzg_commit(ctx, s, s->lagrange_brp, s->tab_lagrange, s->c_single, kzg::N, s->d_q, 1, proof);
-}
+} DVN_CATCH
 
-extern "C" int32_t dvn_kzg_compute_cell_proofs(dvn_ctx* ctx, const dvn_kzg_setup* s, const uint8_t* blob, uint8_t* proofs /* 128 x 48 */) {
+extern "C" int32_t dvn_kzg_compute_cell_proofs(dvn_ctx* ctx, const dvn_kzg_setup* s, const uint8_t* blob, uint8_t* proofs /* 128 x 48 */) try {
     TRY(enter(ctx));
     if (!s || !blob || !proofs) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     if (!s->monomial) return fail(DVN_ERR_INVALID_ARG, "setup was loaded without the monomial G1 basis: no cell proofs");
@@ -524,4 +524,4 @@ extern "C" int32_t dvn_kzg_compute_cell_proofs(dvn_ctx* ctx, const dvn_kzg_setup
     kzg::k_cell_quotients<<<kzg::CELLS * kzg::CELL / 64, 64, 0, ctx->stream>>>(s->d_f, s->d_small + 16, s->d_cellq);
     HIP_TRY(hipGetLastError());
     return kzg_commit(ctx, s, s->monomial, s->tab_monomial, s->c_cells, kzg::QN, s->d_cellq, kzg::CELLS, proofs);
-}
+} DVN_CATCH

@@ -86,3 +86,14 @@ def sharded_groth16_prove(key, witness, r_mont, s_mont, rank: int, world: int, d
     the same proof on the host (dvn_groth16_prove_combine)."""
     part = key.prove_shard(witness, rank, world)
     return key.prove_combine(all_gather_rows(part, world, dist, device), r_mont, s_mont)
+
+
+def sharded_groth16_prove_committed(key, witness, r_mont, s_mont, rank: int, world: int, dist=None, device="cuda") -> dict:
+    """The statetransition shape proper (8 public inputs + ONE BSB22 commitment) shared across the ranks: every rank runs the
+    commitment hint, the keccak challenge and the witness completion whole (replicated: the commitment bases are small), then
+    its entry share of the five MSMs (dvn_groth16_prove_committed_shard); ONE all-gather of 576 bytes per rank; every rank
+    assembles the same proof (dvn_groth16_prove_combine) and holds the same Commitment / CommitmentPok."""
+    part = key.prove_committed_shard(witness, rank, world)
+    proof = key.prove_combine(all_gather_rows(part["partial"], world, dist, device), r_mont, s_mont)
+    proof.update({k: part[k] for k in ("Commitment", "CommitmentPok", "challenge")})
+    return proof

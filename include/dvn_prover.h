@@ -17,6 +17,10 @@
  * (thread-local).  A cgo caller must therefore pin its goroutine to the OS thread across the failing call and the
  * dvn_last_error call (runtime.LockOSThread / UnlockOSThread, as the shim in integration/go does); dvn_error_string(code)
  * is the thread-independent fallback text of a code.
+ *
+ * No C++ exception crosses this boundary: every entry point that returns a code catches whatever is thrown beneath it
+ * (std::bad_alloc of a host container, std::system_error of a thread that cannot start) and returns DVN_ERR_OOM, or
+ * DVN_ERR_DEVICE for anything else, with the message in dvn_last_error.
  */
 #ifndef DVN_PROVER_H
 #define DVN_PROVER_H
@@ -53,6 +57,10 @@ int32_t dvn_ctx_device_ordinal(const dvn_ctx* ctx);
 const char* dvn_last_error(const dvn_ctx* ctx);
 const char* dvn_error_string(int32_t code);
 const char* dvn_version(void);
+/* Test hook, host only (no context, no device): raises the C++ exception `kind` names inside an entry point so that the
+ * exception-to-code mapping of the boundary can be checked.  0 none (DVN_OK), 1 std::bad_alloc, 2 std::system_error (both
+ * DVN_ERR_OOM), 3 std::runtime_error, 4 a non-standard exception (both DVN_ERR_DEVICE).  No counterpart in the reference. */
+int32_t dvn_test_raise(int32_t kind);
 
 /* ---- device memory helpers (bench/test harness; also used by the host orchestration) ------------------ */
 int32_t dvn_malloc(dvn_ctx* ctx, size_t bytes, void** dptr);
@@ -140,6 +148,8 @@ int32_t dvn_msm_combine_g1(dvn_ctx* ctx, const uint64_t* window_sums /* nwin x 1
 int32_t dvn_msm_g1_share_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* d_scalars_mont,
                                 uint32_t flags, uint32_t rank, uint32_t world, int32_t* ticket);
 int32_t dvn_msm_g1_share_collect(dvn_ctx* ctx, int32_t ticket, uint64_t partial_jac[12]);
+/* jacs: the NORMALISED images the library emits -- Z is 0 (infinity) or the Montgomery 1; any other Z is DVN_ERR_INVALID_ARG
+ * (a general G1Jac, e.g. gnark's, must be brought to affine first) */
 int32_t dvn_msm_g1_sum(const uint64_t* jacs /* count x 12 */, uint32_t count, uint64_t out_jac[12]);
 
 /* ---- fr/fft (replaces gnark-crypto fft.Domain) ------------------------------------- */
@@ -232,7 +242,8 @@ int32_t dvn_groth16_proof_abi_encode(const uint64_t proof[32], const uint64_t co
  * silent CPU computation.  curve ids: 1 BN254, 2 BLS12-377, 3 BLS12-381, 4 BW6-761 -- the four legs of callGPUProver
  * (prover_gpu.go:27-57), each with a GPU path here; any other id returns "GPU proving not supported for curve ..." like
  * prover_gpu.go:58-60.  witness / r / s / proof have the widths of the curve: scalars 4 uint64 (BW6-761: 6), proofs 32 uint64
- * on BN254, 48 on the two BLS12 curves, 72 on BW6-761.  The package state (UseGPUProver, SetProver, the CPU backend) may be
+ * on BN254, 48 on the two BLS12 curves, 72 on BW6-761 -- plus 16 for a BN254 key with a BSB22 commitment, whose proof image
+ * continues with Commitments[0] | CommitmentPok (dvn_groth16_proof_words gives the size for a key).  The package state (UseGPUProver, SetProver, the CPU backend) may be
  * read and written from any thread. */
 typedef struct dvn_prover_request {
     int curve; dvn_ctx* ctx; const dvn_r1cs* ccs; dvn_groth16_pk* pk;
@@ -446,6 +457,24 @@ int32_t dvn_r1cs_synthetic_committed(uint64_t seed, uint32_t n_constraints, uint
 int32_t dvn_groth16_prove_committed(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
                                     const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32],
                                     uint64_t commitment_out[8], uint64_t pok_out[8], uint64_t challenge_out[4]);
+/* The committed proof shared between GPUs -- the statetransition proof is the node's serialisation point
+ * (/root/reference/sequencer/statetransition.go:80,248) and its key carries exactly one commitment
+ * (/root/reference/config/statetransition_vkey.sol:97-114,659-676).  Rank `rank` of `world` runs the commitment hint, the
+ * challenge and the witness completion whole (the commitment bases are small; replicating them spares an exchange before the
+ * challenge) and then its entry share of the five MSMs: partial_out as dvn_groth16_prove_shard, assembled by
+ * dvn_groth16_prove_combine; every rank returns the same commitment, PoK and challenge.  _multi does the same over the devices
+ * of a multi-device context from one call (keys[i] = the key on dvn_ctx_device(ctx, i)). */
+int32_t dvn_groth16_prove_committed_shard(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
+                                          uint32_t rank, uint32_t world, uint64_t partial_out[72],
+                                          uint64_t commitment_out[8], uint64_t pok_out[8], uint64_t challenge_out[4]);
+int32_t dvn_groth16_prove_committed_multi(dvn_ctx* ctx, dvn_groth16_pk* const* keys, uint32_t nkeys, const uint64_t* witness,
+                                          const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32],
+                                          uint64_t commitment_out[8], uint64_t pok_out[8], uint64_t challenge_out[4]);
+/* uint64 words of the proof image dvn_prover_prove / dvn_prover_gpu_prover write for this key: Ar | Bs | Krs of the key's curve
+ * (32 on BN254, 48 on the BLS12 curves, 72 on BW6-761), followed by Commitments[0] | CommitmentPok (two G1Affine images, +16
+ * on BN254) when the key carries a BSB22 commitment -- gnark's Proof holds those two fields beside Ar, Bs, Krs, and
+ * callGPUProver routes such a key to the committed prover. */
+int32_t dvn_groth16_proof_words(const dvn_groth16_pk* pk, size_t* words);
 int32_t dvn_keccak256(const uint8_t* data, size_t len, uint8_t out[32]);     /* host only: Solidity's keccak256 */
 
 /* ---- Blob KZG on BLS12-381 (EIP-4844 / EIP-7594) ------------------------------------------------
@@ -475,13 +504,15 @@ int32_t dvn_kzg_compute_cell_proofs(dvn_ctx* ctx, const dvn_kzg_setup* setup, co
 int32_t dvn_kzg_evaluate_barycentric(dvn_ctx* ctx, const dvn_kzg_setup* setup, const uint8_t* blob, const uint8_t z[32], uint8_t y[32]);
 
 /* ---- the entry point that allocates nothing ------------------------------------------------------------------------
- * No counterpart in the reference: this one is for callers that cannot call hipMalloc -- code under HIP graph capture,
- * tight serving loops, harnesses that forbid allocation.  Same MSM and same result as dvn_msm_g1, but every scratch array
+ * No counterpart in the reference: this one is for callers that cannot call hipMalloc -- tight serving loops, harnesses
+ * that forbid allocation, code that must leave the allocator alone.  (It is NOT capturable into a HIP graph: the call
+ * synchronises its stream and finishes the result on the host.)  Same MSM and same result as dvn_msm_g1, but every scratch array
  * of the pipeline (digits, sort buffers, bucket sums, edge partials) lives in a fixed 64 MiB device array that the library
  * holds on each GPU it runs on until the process ends, and memory is cleared by fill kernels.  Limits: n <=
  * DVN_MSM_STATIC_MAX_N, scalars in DEVICE memory (flags must carry DVN_MSM_SCALARS_ON_DEVICE), BN254 G1; anything beyond
  * is DVN_ERR_INVALID_ARG with a message that names the limit.  Calls no hipMalloc / hipFree.  Every call on one GPU shares
- * that GPU's array: calls that overlap on one GPU (two contexts on the same device) race. */
+ * that GPU's array; the library serialises its own calls per GPU (a process-wide lock per device ordinal, so sibling contexts
+ * of one dvn_init cannot corrupt each other) -- they queue, they do not overlap. */
 #define DVN_MSM_STATIC_MAX_N 65536u
 int32_t dvn_msm_g1_static(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* d_scalars_mont,
                           uint32_t flags, uint64_t out_jac[12]);

@@ -64,3 +64,43 @@ def test_header_is_plain_c():
         src = os.path.join(d, "hdr.c")
         open(src, "w").write('#include "dvn_prover.h"\nint main(void) { return 0; }\n')
         subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), "-fsyntax-only", src])
+
+
+def test_no_exception_crosses_the_boundary(pkg):
+    """bad_alloc / system_error thrown beneath an entry point come back as DVN_ERR_OOM, anything else as DVN_ERR_DEVICE, each
+    with a message (dvn_test_raise throws from inside a guarded entry point; host only)."""
+    L = pkg.load_library()
+    assert L.dvn_test_raise(0) == 0
+    for kind, code, word in ((1, -4, b"bad_alloc"), (2, -4, b"exhausted"), (3, -2, b"injected"), (4, -2, b"unknown")):
+        assert L.dvn_test_raise(kind) == code
+        assert word in L.dvn_last_error(None)
+
+
+def test_every_code_returning_entry_point_is_guarded():
+    """Source check: each extern "C" definition that returns a code is a function-try-block closed by DVN_CATCH."""
+    import glob
+    csrc = os.path.join(ROOT, "davinci-node_amd", "csrc")
+    n = 0
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
+        lines = open(path).read().split("\n")
+        i = 0
+        while i < len(lines):
+            if lines[i].startswith('extern "C" int32_t'):
+                j = i
+                while not lines[j].rstrip().endswith(("{", ";", "}", "DVN_CATCH")):
+                    j += 1
+                if lines[j].rstrip().endswith(";"):            # declaration
+                    i = j + 1
+                    continue
+                assert "try {" in lines[j], f"{path}:{j + 1}: entry point without a function-try-block"
+                if not lines[j].rstrip().endswith("DVN_CATCH"):
+                    k = j + 1
+                    while not lines[k].startswith("}"):
+                        k += 1
+                    assert lines[k].startswith("} DVN_CATCH"), f"{path}:{k + 1}: entry point not closed by DVN_CATCH"
+                    j = k
+                n += 1
+                i = j + 1
+                continue
+            i += 1
+    assert n >= 120

@@ -72,13 +72,14 @@ def test_writer_point_encodings_round_trip(opy):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("raw,domain_flag", [(False, True), (True, True), (False, False)])
-def test_key_file_round_trip_proves(ctx, pkg, opy, orc, tmp_path, raw, domain_flag):
+@pytest.mark.parametrize("n_c,raw,domain_flag", [(1500, False, True), (1500, True, True), (1500, False, False), (1 << 16, False, True)])
+def test_key_file_round_trip_proves(ctx, pkg, opy, orc, tmp_path, n_c, raw, domain_flag):
     """Setup -> export -> WRITE the gnark layout -> dvn_groth16_pk_load_file -> prove from the solver's output: the proof of the
-    original key, and the trapdoor closed form.  Also: content hash check, cache hit on the second load."""
+    original key, and the trapdoor closed form.  Also: content hash check, cache hit on the second load.  At 2^16 constraints
+    every point slice holds >= 2^15 points, so the loader builds expanded tables (the branch every real key takes) and the
+    proof runs over them."""
     from oracle import gnark_key_format_py as fmt
     o = opy
-    n_c = 1500
     cs = pkg.R1CS(7, n_c, 9)
     key = pkg.Groth16Key(ctx, cs, 3)
     arrays = key.export_arrays(cs.n_wires, cs.n_public)
@@ -92,6 +93,8 @@ def test_key_file_round_trip_proves(ctx, pkg, opy, orc, tmp_path, raw, domain_fl
     assert "hash mismatch" in str(e.value)
     lk = pkg.LoadedKey(ctx, path, cs.n_public, sha256_hex=digest)
     assert lk.log_n == key.log_n
+    if n_c >= 1 << 16:
+        assert min(lk.sizes[k] for k in ("A", "B", "K", "Z", "B2")) >= 1 << 15, "every slice must take the expanded-table branch"
     ref = o.SyntheticR1CS(n_c, 9, 7)
     a, b, c = (np.array([o.limbs(o.to_mont(v, R)) for v in col], dtype=np.uint64) for col in ref.abc())
     r, s = mont(o, 1234567), mont(o, 7654321)

@@ -159,15 +159,66 @@ def test_plain_prover_refuses_a_committed_key(ctx, pkg, opy):
     part = np.zeros(72, dtype=np.uint64)
     assert L.dvn_groth16_prove_shard(ctx.h, key.h, w.ctypes.data, 0, 0, 2, part.ctypes.data) == -1
     assert L.dvn_groth16_prove_solved(ctx.h, key.h, w.ctypes.data, w.ctypes.data, w.ctypes.data, w.ctypes.data, 10, r.ctypes.data, s.ctypes.data, out.ctypes.data) == -1
-    # the prover-package mirror reports the failure as the GPU error (and would fall back to the CPU prover)
+    # the prover-package mirror routes such a key to the committed prover (callGPUProver): its proof image continues with
+    # Commitments[0] | CommitmentPok, as gnark's Proof does -- dvn_groth16_proof_words says how long it is
+    assert key.proof_words() == 48
     L.dvn_prover_set_use_gpu(1)
     L.dvn_prover_set_cpu_backend(None, None)
-    assert L.dvn_prover_prove(ctx.h, 1, cs.h, key.h, w.ctypes.data, r.ctypes.data, s.ctypes.data, out.ctypes.data) != 0
+    L.dvn_prover_set_prover(None, None)
+    out48 = np.zeros(48, dtype=np.uint64)
+    assert L.dvn_prover_prove(ctx.h, 1, cs.h, key.h, w.ctypes.data, r.ctypes.data, s.ctypes.data, out48.ctypes.data) == 0
+    assert L.dvn_prover_last_backend() == 1
     L.dvn_prover_set_use_gpu(0)
-    got = key.prove_committed(w, r, s)                              # the right entry point works, before and after
+    got = key.prove_committed(w, r, s)                              # the entry point itself, before and after
     want = o.groth16_committed_expected(o.SyntheticR1CSCommitted(200, 9, 8, 7), 3, 1, 2)
     assert list(got["Krs"]) == o.g1_to_limbs(want["Krs"])
+    assert (out48[0:8] == got["Ar"]).all() and (out48[8:24] == got["Bs"]).all() and (out48[24:32] == got["Krs"]).all()
+    assert (out48[32:40] == got["Commitment"]).all() and (out48[40:48] == got["CommitmentPok"]).all()
     key.free(); cs.free()
+
+
+@pytest.mark.gpu
+def test_committed_proof_shared_by_ranks_and_by_devices(pkg, opy):
+    """The statetransition shape (8 public inputs + one BSB22 commitment) shared between GPUs: per-rank shares
+    (dvn_groth16_prove_committed_shard + _combine, worlds 1, 2, 3, 8 played by one process) and the one-call form over a
+    three-"device" context (dvn_groth16_prove_committed_multi) both reproduce the single-device committed proof and the
+    oracle's closed form (commitment, PoK, challenge, Ar, Bs, Krs) bit for bit.  2^16 constraints: every large key set is an
+    expanded table, so every rank runs a real entry range; the 2^12 commitment bases are replicated."""
+    o = opy
+    n_c, n_cm = 1 << 16, 1 << 12
+    mc = pkg.Context([0, 0, 0])
+    cs = pkg.R1CS(7, n_c, 9, n_committed=n_cm)
+    keys = [pkg.Groth16Key(mc.device(i), cs, 3) for i in range(3)]
+    w = cs.witness()
+    r, s = mont(o, 1234567), mont(o, 7654321)
+    want = o.groth16_committed_expected(o.SyntheticR1CSCommitted(n_c, 9, n_cm, 7), 3, 1234567, 7654321)
+    def check(got, tag):
+        assert list(got["Commitment"]) == o.g1_to_limbs(want["Commitment"]), tag
+        assert list(got["CommitmentPok"]) == o.g1_to_limbs(want["CommitmentPok"]), tag
+        assert list(got["challenge"]) == o.limbs(o.to_mont(want["challenge"], R)), tag
+        assert list(got["Ar"]) == o.g1_to_limbs(want["Ar"]) and list(got["Bs"]) == o.g2_to_limbs(want["Bs"]), tag
+        assert list(got["Krs"]) == o.g1_to_limbs(want["Krs"]), tag
+    check(keys[0].prove_committed(w, r, s), "single")
+    from davinci_node_amd import sharding
+    for world in (1, 2, 3, 8):
+        shares = [keys[0].prove_committed_shard(w, rank, world) for rank in range(world)]
+        got = keys[0].prove_combine(np.stack([sh["partial"] for sh in shares]), r, s)
+        got.update({k: shares[-1][k] for k in ("Commitment", "CommitmentPok", "challenge")})
+        check(got, f"world {world}")
+        assert all((sh["Commitment"] == shares[0]["Commitment"]).all() for sh in shares)
+    check(sharding.sharded_groth16_prove_committed(keys[0], w, r, s, 0, 1), "helper, world 1")
+    check(pkg.prove_committed_multi(mc, keys, w, r, s), "multi")
+    # a plain key is refused by the committed entry points; the plain multi-device prover names the right call for a committed key
+    cs0 = pkg.R1CS(7, 300, 9); k0 = [pkg.Groth16Key(mc.device(i), cs0, 3) for i in range(3)]
+    with pytest.raises(pkg.DvnError):
+        pkg.prove_committed_multi(mc, k0, cs0.witness(), r, s)
+    with pytest.raises(pkg.DvnError) as e:
+        pkg.prove_multi(mc, keys, w, r, s)
+    assert "dvn_groth16_prove_committed_multi" in str(e.value)
+    check(pkg.prove_committed_multi(mc, keys, w, r, s), "multi, after the refusals")
+    for k in k0 + keys:
+        k.free()
+    cs0.free(); cs.free(); mc.close()
 
 
 @pytest.mark.gpu

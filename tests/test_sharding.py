@@ -117,3 +117,32 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["result_checked"] is True and line["value"] > 0
     assert line["roofline"]["pairs_per_launch"] == (1 << 20) // 2        # per-rank algorithmic bytes, not the whole MSM's
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_extras_prove_the_committed_statetransition_shape():
+    """`bench.py --gpus 2` WITH its multi-GPU extras (two ranks on the one GPU, gloo): the sharded leg proves the 8-public +
+    1-commitment key (BASELINE config 5's shape), all ranks hold the same proof, it equals the single-GPU proof, and the
+    process exits 0."""
+    import json
+    import subprocess
+    env = dict(os.environ, DVN_BENCH_BACKEND="gloo", DVN_BENCH_EXTRAS_LIMIT_S="250")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29900 + os.getpid() % 90), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--log-n", "20", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=290, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    ex = line["extras"]
+    assert "error" not in ex, ex
+    sh = ex["groth16_sharded_2^20"]
+    assert sh["ranks"] == 2 and sh["all_ranks_same_proof"] is True and sh["equals_single_gpu_proof"] is True and "1 commitment" in sh["shape"]
+    assert ex["groth16_replicas_2^20"]["post_solver_proofs_per_s"] > 0
+
+
+def test_bench_exit_status_reports_failed_extras():
+    """Source-level contract of bench.py's N > 1 tail: both failure paths (watchdog, exception in the extras) leave with a
+    non-zero status after printing the line, never 0."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tail = src[src.index("def bail():"):]
+    assert tail.count("os._exit(3)") == 2 and "os._exit(0)" not in src
