@@ -178,6 +178,13 @@ def load_library():
         "dvn_gnark_pk_scan": (i32, [vp, sz, vp]),
         "dvn_groth16_pk_load_bytes": (i32, [vp, vp, sz, u32, vp, u32, C.POINTER(vp)]),
         "dvn_groth16_pk_load_file": (i32, [vp, C.c_char_p, C.c_char_p, u32, vp, u32, C.POINTER(vp)]),
+        "dvn_groth16_pk_evict": (i32, [vp, vp]),
+        "dvn_bls12377_gnark_pk_scan": (i32, [vp, sz, vp]),
+        "dvn_bls12377_groth16_pk_load_bytes": (i32, [vp, vp, sz, u32, vp, u32, C.POINTER(vp)]),
+        "dvn_bls12377_groth16_pk_load_file": (i32, [vp, C.c_char_p, C.c_char_p, u32, vp, u32, C.POINTER(vp)]),
+        "dvn_bw6761_gnark_pk_scan": (i32, [vp, sz, vp]),
+        "dvn_bw6761_groth16_pk_load_bytes": (i32, [vp, vp, sz, u32, vp, u32, C.POINTER(vp)]),
+        "dvn_bw6761_groth16_pk_load_file": (i32, [vp, C.c_char_p, C.c_char_p, u32, vp, u32, C.POINTER(vp)]),
         "dvn_groth16_pk_commitment_bases": (i32, [vp, C.POINTER(vp), C.POINTER(vp)]),
         "dvn_prover_use_gpu": (i32, []),
         "dvn_prover_set_use_gpu": (None, [i32]),
@@ -225,7 +232,9 @@ EXPORTED_SYMBOLS = [
     "dvn_msm_g1_share_submit", "dvn_msm_g1_share_collect", "dvn_msm_g1_sum",
     "dvn_groth16_prove_multi", "dvn_groth16_prove_solved_multi", "dvn_bw6761_groth16_prove_solved_multi", "dvn_groth16_last_stats_json",
     "dvn_bls12377_pedersen_commit", "dvn_bls12381_pedersen_commit", "dvn_bw6761_pedersen_commit",
-    "dvn_gnark_pk_scan", "dvn_groth16_pk_load_bytes", "dvn_groth16_pk_load_file", "dvn_groth16_pk_commitment_bases",
+    "dvn_gnark_pk_scan", "dvn_groth16_pk_load_bytes", "dvn_groth16_pk_load_file", "dvn_groth16_pk_commitment_bases", "dvn_groth16_pk_evict",
+    "dvn_bls12377_gnark_pk_scan", "dvn_bls12377_groth16_pk_load_bytes", "dvn_bls12377_groth16_pk_load_file",
+    "dvn_bw6761_gnark_pk_scan", "dvn_bw6761_groth16_pk_load_bytes", "dvn_bw6761_groth16_pk_load_file",
 ]
 
 # (curve, ccs, pk, witness, r, s, proof, user): what the reference's CPUProverWithWitness receives
@@ -695,31 +704,34 @@ def prove_committed_multi(ctx: "Context", keys, witness: np.ndarray, r_mont, s_m
     return {"Ar": out[0:8].copy(), "Bs": out[8:24].copy(), "Krs": out[24:32].copy(), "Commitment": cm, "CommitmentPok": pok, "challenge": ch}
 
 
-def gnark_pk_scan(data: bytes) -> dict:
-    """Host only: the section sizes of a gnark BN254 proving-key image (dvn_gnark_pk_scan)."""
+def gnark_pk_scan(data: bytes, curve: str = "bn254") -> dict:
+    """Host only: the section sizes of a gnark proving-key image of `curve` (dvn_[<curve>_]gnark_pk_scan)."""
     L = load_library()
-    info = (C.c_uint64 * 11)()
-    rc = L.dvn_gnark_pk_scan(data, len(data), info)
+    info = (C.c_uint64 * 12)()
+    fn = L.dvn_gnark_pk_scan if curve == "bn254" else getattr(L, f"dvn_{curve}_gnark_pk_scan")
+    rc = fn(data, len(data), info)
     if rc != 0:
         raise DvnError(rc, L.dvn_last_error(None).decode())
-    names = ("log_n", "raw", "n_wires", "A", "B", "Z", "K", "B2", "n_commitments", "basis0", "domain_flag")
+    names = ("log_n", "raw", "n_wires", "A", "B", "Z", "K", "B2", "n_commitments", "basis0", "domain_flag", "bitmap_prefix")
     return dict(zip(names, (int(v) for v in info)))
 
 
 class LoadedKey:
-    """A proving key read from a gnark artifact file / image (dvn_groth16_pk_load_file / _load_bytes, BN254): proofs come from
+    """A proving key read from a gnark artifact file / image (dvn_[<curve>_]groth16_pk_load_file / _load_bytes): proofs come from
     the solver's output like ImportedKey's.  n_public and the committed private wires come from the constraint system gnark
     loads next to the key."""
 
-    def __init__(self, ctx: "Context", source, n_public: int, committed_wires=(), sha256_hex: str | None = None):
-        self.ctx, self._a1, self._a2, self._prefix = ctx, 8, 16, "dvn_"
+    def __init__(self, ctx: "Context", source, n_public: int, committed_wires=(), sha256_hex: str | None = None, curve: str = "bn254"):
+        a1 = {"bn254": 8, "bw6761": 24}.get(curve, 12)
+        self.ctx, self._a1, self._a2 = ctx, a1, (a1 if curve == "bw6761" else 2 * a1)
+        self._prefix = "dvn_" if curve == "bn254" else f"dvn_{curve}_"
         cw = np.ascontiguousarray(committed_wires, dtype=np.uint32)
         cwp = C.c_void_p(cw.ctypes.data) if cw.size else None
         h = C.c_void_p()
         if isinstance(source, (bytes, bytearray)):
-            ctx._chk(ctx.L.dvn_groth16_pk_load_bytes(ctx.h, bytes(source), len(source), n_public, cwp, cw.size, C.byref(h)))
+            ctx._chk(getattr(ctx.L, self._prefix + "groth16_pk_load_bytes")(ctx.h, bytes(source), len(source), n_public, cwp, cw.size, C.byref(h)))
         else:
-            ctx._chk(ctx.L.dvn_groth16_pk_load_file(ctx.h, str(source).encode(), sha256_hex.encode() if sha256_hex else None, n_public, cwp, cw.size, C.byref(h)))
+            ctx._chk(getattr(ctx.L, self._prefix + "groth16_pk_load_file")(ctx.h, str(source).encode(), sha256_hex.encode() if sha256_hex else None, n_public, cwp, cw.size, C.byref(h)))
         self.h = h
         ln = C.c_uint32(); sizes = (C.c_uint64 * 5)()
         ctx.L.dvn_groth16_pk_info(h, C.byref(ln), sizes)
@@ -740,6 +752,12 @@ class LoadedKey:
     def free(self):
         if self.h:
             self.ctx._chk(self.ctx.L.dvn_groth16_pk_free(self.ctx.h, self.h))
+            self.h = None
+
+    def evict(self):
+        """Drop the key from the context's sha256 cache and release it (every handle to it becomes invalid)."""
+        if self.h:
+            self.ctx._chk(self.ctx.L.dvn_groth16_pk_evict(self.ctx.h, self.h))
             self.h = None
 
 

@@ -4,6 +4,7 @@
 // R = 2^384), Fe2 with u^2 = -5 for G2, and the 253-bit scalar field (two-adicity 47, coset shift 22) for the NTT.
 #include "suite_api.h"
 #include "groth16_impl.h"
+#include "artifacts_impl.h"
 
 static G1_377::A g1_377_generator() {      // gnark-crypto bls12-377 G1 generator, Montgomery image (oracle/curves_py.py BLS12_377.g1_gen)
     static const u64 g[12] = {0x260f33b9772451f4ULL, 0xc54dd773169d5658ULL, 0x5c1551c469a510ddULL, 0x761662e4425e1698ULL, 0xc97d78cc6f065272ULL, 0x00a41206b361fd4dULL,
@@ -95,4 +96,31 @@ extern "C" int32_t dvn_bls12377_groth16_pk_export_arrays(dvn_ctx* ctx, const dvn
 extern "C" int32_t dvn_bls12377_pedersen_commit(dvn_ctx* ctx, const dvn_points* basis, const dvn_points* basis_exp_sigma, const uint64_t* values_mont,
                                                 size_t n, uint32_t flags, uint64_t commitment_out[12], uint64_t pok_out[12]) try {
     return pedersen_commit<SuiteBls12377>(ctx, basis, basis_exp_sigma, values_mont, n, flags, commitment_out, pok_out);
+} DVN_CATCH
+
+
+// ---- the voteverifier's proving key as the node stores it (gnark pk.WriteTo, /root/reference/cmd/circuit-compile/main.go:507-513;
+// loaded at boot for the voteverifier circuit, /root/reference/sequencer/circuit_artifacts.go:39-76): artifacts_impl.h on this
+// curve -- 48-byte coordinates, three flag bits, Tonelli-Shanks square roots (p = 1 mod 4, two-adicity 46) ------------------------
+namespace dvn_art {
+template <> struct KeyTraits<SuiteBls12377> {
+    static constexpr const char* NAME = "BLS12-377";
+    static constexpr u32 COSET_GEN = 22;                                  // fr.MultiplicativeGen of BLS12-377
+    static constexpr u32 NON_RESIDUE = 5;                                 // u^2 = -5 is irreducible and -1 is a square (p = 1 mod 4)
+    static CurveAux1<Fp377Cfg> aux_g1() { return make_aux1<Fp377Cfg>(fe_one<Fp377Cfg>(), NON_RESIDUE); }               // y^2 = x^3 + 1
+    static CurveAux2<Fp377Cfg> aux_g2() {                                                                           // twist: y^2 = x^3 + 1/u = x^3 - u/5
+        typedef Ops<Fp377> O;
+        const Fp377 fifth = O::inv(fe_from_canonical<Fp377Cfg>(fe_small<Fp377Cfg>(5)));
+        return make_aux2<Fp377Cfg>(Fp2_377{fe_zero<Fp377Cfg>(), O::neg(fifth)}, NON_RESIDUE);
+    }
+};
+}  // namespace dvn_art
+extern "C" int32_t dvn_bls12377_gnark_pk_scan(const uint8_t* data, size_t len, uint64_t info[12]) try { return dvn_art::pk_scan_api<SuiteBls12377>(data, len, info); } DVN_CATCH
+extern "C" int32_t dvn_bls12377_groth16_pk_load_bytes(dvn_ctx* ctx, const uint8_t* data, size_t len, uint32_t n_public, const uint32_t* committed_wires,
+                                                      uint32_t n_committed_wires, dvn_groth16_pk** out) try {
+    return dvn_art::pk_load_bytes_api<SuiteBls12377>(ctx, data, len, n_public, committed_wires, n_committed_wires, out);
+} DVN_CATCH
+extern "C" int32_t dvn_bls12377_groth16_pk_load_file(dvn_ctx* ctx, const char* path, const char* sha256_hex, uint32_t n_public,
+                                                     const uint32_t* committed_wires, uint32_t n_committed_wires, dvn_groth16_pk** out) try {
+    return dvn_art::pk_load_file_api<SuiteBls12377>(ctx, path, sha256_hex, n_public, committed_wires, n_committed_wires, out);
 } DVN_CATCH

@@ -8,6 +8,7 @@
 // overflow 64 bits).
 #include "suite_api.h"
 #include "groth16_impl.h"
+#include "artifacts_impl.h"
 
 static int32_t check_group(int group) { return (group == 1 || group == 2) ? DVN_OK : fail(DVN_ERR_INVALID_ARG, "group must be 1 (G1) or 2 (G2)"); }
 
@@ -142,4 +143,26 @@ extern "C" int32_t dvn_bw6761_groth16_prove_solved_multi(dvn_ctx* ctx, dvn_groth
     if (!a || !b || !c) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
     const uint64_t* src[3] = {a, b, c};
     return groth16_prove_multi<SuiteBw6761>(ctx, keys, nkeys, w, 0u, src, len, r_mont, s_mont, proof_out);
+} DVN_CATCH
+
+
+// ---- the aggregator's proving key as the node stores it (gnark pk.WriteTo, /root/reference/cmd/circuit-compile/main.go:507-513;
+// loaded at boot for the aggregator circuit, /root/reference/sequencer/circuit_artifacts.go:39-76): artifacts_impl.h on this
+// curve -- 96-byte coordinates, three flag bits, a^((p + 1) / 4) square roots, both groups curves over Fp ------------------------
+namespace dvn_art {
+template <> struct KeyTraits<SuiteBw6761> {
+    static constexpr const char* NAME = "BW6-761";
+    static constexpr u32 COSET_GEN = 15;                                  // fr.MultiplicativeGen of BW6-761
+    static CurveAux1<Fp761Cfg> aux_g1() { return make_aux1<Fp761Cfg>(Ops<Fp761>::neg(fe_one<Fp761Cfg>()), 0); }                          // y^2 = x^3 - 1
+    static CurveAux1<Fp761Cfg> aux_g2() { return make_aux1<Fp761Cfg>(fe_from_canonical<Fp761Cfg>(fe_small<Fp761Cfg>(4)), 0); }            // y^2 = x^3 + 4
+};
+}  // namespace dvn_art
+extern "C" int32_t dvn_bw6761_gnark_pk_scan(const uint8_t* data, size_t len, uint64_t info[12]) try { return dvn_art::pk_scan_api<SuiteBw6761>(data, len, info); } DVN_CATCH
+extern "C" int32_t dvn_bw6761_groth16_pk_load_bytes(dvn_ctx* ctx, const uint8_t* data, size_t len, uint32_t n_public, const uint32_t* committed_wires,
+                                                    uint32_t n_committed_wires, dvn_groth16_pk** out) try {
+    return dvn_art::pk_load_bytes_api<SuiteBw6761>(ctx, data, len, n_public, committed_wires, n_committed_wires, out);
+} DVN_CATCH
+extern "C" int32_t dvn_bw6761_groth16_pk_load_file(dvn_ctx* ctx, const char* path, const char* sha256_hex, uint32_t n_public,
+                                                   const uint32_t* committed_wires, uint32_t n_committed_wires, dvn_groth16_pk** out) try {
+    return dvn_art::pk_load_file_api<SuiteBw6761>(ctx, path, sha256_hex, n_public, committed_wires, n_committed_wires, out);
 } DVN_CATCH

@@ -78,6 +78,8 @@ struct dvn_groth16_pk {
     size_t nK = 0;
     bool imported = false;
     bool cached = false;                // owned by the context's sha256-keyed key cache: dvn_groth16_pk_free leaves it alone
+    u32 load_n_public = 0;              // what a key read from an artifact file was loaded with: a cache hit must name the same
+    std::vector<u32> load_committed;
     // verifying key as gnark affine Montgomery images (uint64 words): alpha (G1) | beta | gamma | delta (G2) | IC[n_public] (G1:
     // CONSTANT, PUB_i of the Solidity verifier) | Pedersen G | Pedersen GSigmaNeg (G2; only with a commitment)
     std::vector<uint64_t> vk_words;

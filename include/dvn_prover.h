@@ -427,20 +427,37 @@ int32_t dvn_bw6761_groth16_pk_export_arrays(dvn_ctx* ctx, const dvn_groth16_pk* 
  * The node keeps proving keys as sha256-named files written by cmd/circuit-compile with pk.WriteTo
  * (/root/reference/cmd/circuit-compile/main.go:507-513) and loads them with pk.UnsafeReadFrom
  * (/root/reference/circuits/artifacts.go:391-406, hash check :123-133).  dvn_groth16_pk_load_file reads the same bytes
- * (BN254; compressed or raw point encodings) straight into a device-resident key for dvn_groth16_prove_solved: the points
+ * (compressed or raw point encodings) straight into a device-resident key for dvn_groth16_prove_solved: the points
  * are decompressed on the device, the InfinityA / InfinityB bitmaps become the wire lists of A and B, and K's wire list is
  * [n_public, nbWires) minus committed_wires -- the two facts the key file does not carry come from the constraint system
  * gnark loads beside it: ccs.GetNbPublicVariables(), and for committed_wires every private wire whose K point gnark's Setup
  * leaves out of pk.G1.K, i.e. the PrivateCommitted indices of the commitment TOGETHER WITH its CommitmentIndex wire (the wire
  * that receives the challenge: Setup moves its K point into the verifying key).  The count is checked against |G1.K|.
- * A cache hit returns the resident key without looking at n_public / committed_wires again.  sha256_hex: the
- * expected content hash (the file's name in the node's cache) or NULL; a mismatch is DVN_ERR_INVALID_ARG.  Keys are cached per
- * context by content hash: loading the same file again returns the resident key, and cached keys live until dvn_shutdown
- * (dvn_groth16_pk_free leaves them alone).  _load_bytes: the same reader on a memory image, uncached.  dvn_gnark_pk_scan
- * (host only) reports the section sizes of an image: log_n, raw (0/1), nbWires, |A|, |B|, |Z|, |K|, |G2.B|, nbCommitmentKeys,
- * |Basis[0]|, whether the domain header carries its flag byte.  The format lives in the un-vendored gnark module: it is
- * restated from the published layout and exercised against this repository's own writer only. */
-int32_t dvn_gnark_pk_scan(const uint8_t* data, size_t len, uint64_t info[11]);
+ * sha256_hex: the expected content hash (the file's name in the node's cache) or NULL; a mismatch is DVN_ERR_INVALID_ARG.
+ * Keys are cached per context by content hash: loading the same file again returns the resident key -- provided the call names
+ * the same n_public and committed_wires as the load that created it (anything else is DVN_ERR_INVALID_ARG) -- and cached keys
+ * live until dvn_groth16_pk_evict or dvn_shutdown (dvn_groth16_pk_free leaves them alone).  _load_bytes: the same reader on a
+ * memory image, uncached.  dvn_gnark_pk_scan (host only) reports the section sizes of an image: log_n, raw (0/1), nbWires, |A|,
+ * |B|, |Z|, |K|, |G2.B|, nbCommitmentKeys, |Basis[0]|, whether the domain header carries its flag byte, whether the two []bool
+ * bitmaps carry a uint32 length (both variants of each are accepted; the header's fields must agree with each other --
+ * CardinalityInv * Cardinality = 1, Generator a primitive root of that order, the curve's coset generator -- so a misread
+ * header is rejected rather than parsed further).  The format lives in the un-vendored gnark module: it is restated from the
+ * published layout and exercised against this repository's own writer only.
+ * The node loads four circuits' keys at boot (/root/reference/sequencer/circuit_artifacts.go:39-76): the voteverifier's
+ * (BLS12-377: 48-byte coordinates, three flag bits, Tonelli-Shanks roots) and the aggregator's (BW6-761: 96-byte coordinates,
+ * both groups over Fp) have the same three calls under their curve's prefix, feeding dvn_<curve>_groth16_prove_solved. */
+int32_t dvn_gnark_pk_scan(const uint8_t* data, size_t len, uint64_t info[12]);
+int32_t dvn_groth16_pk_evict(dvn_ctx* ctx, dvn_groth16_pk* pk);      /* drop a cached key from the cache and free it */
+int32_t dvn_bls12377_gnark_pk_scan(const uint8_t* data, size_t len, uint64_t info[12]);
+int32_t dvn_bls12377_groth16_pk_load_bytes(dvn_ctx* ctx, const uint8_t* data, size_t len, uint32_t n_public, const uint32_t* committed_wires,
+                                           uint32_t n_committed_wires, dvn_groth16_pk** out);
+int32_t dvn_bls12377_groth16_pk_load_file(dvn_ctx* ctx, const char* path, const char* sha256_hex, uint32_t n_public,
+                                          const uint32_t* committed_wires, uint32_t n_committed_wires, dvn_groth16_pk** out);
+int32_t dvn_bw6761_gnark_pk_scan(const uint8_t* data, size_t len, uint64_t info[12]);
+int32_t dvn_bw6761_groth16_pk_load_bytes(dvn_ctx* ctx, const uint8_t* data, size_t len, uint32_t n_public, const uint32_t* committed_wires,
+                                         uint32_t n_committed_wires, dvn_groth16_pk** out);
+int32_t dvn_bw6761_groth16_pk_load_file(dvn_ctx* ctx, const char* path, const char* sha256_hex, uint32_t n_public,
+                                        const uint32_t* committed_wires, uint32_t n_committed_wires, dvn_groth16_pk** out);
 int32_t dvn_groth16_pk_load_bytes(dvn_ctx* ctx, const uint8_t* data, size_t len, uint32_t n_public, const uint32_t* committed_wires,
                                   uint32_t n_committed_wires, dvn_groth16_pk** out);
 int32_t dvn_groth16_pk_load_file(dvn_ctx* ctx, const char* path, const char* sha256_hex, uint32_t n_public,

@@ -18,3 +18,11 @@ func newConstraintSystem(curve ecc.ID) constraint.ConstraintSystem { return grot
 func newProvingKey(curve ecc.ID) groth16.ProvingKey { return groth16.NewProvingKey(curve) }
 
 func newVerifyingKey(curve ecc.ID) groth16.VerifyingKey { return groth16.NewVerifyingKey(curve) }
+
+// preloadDeviceKey is the optional second half of LoadOrDownloadProvingKey under the hip tag (apply_hip_patch.sh adds the one
+// call after pk.UnsafeReadFrom, /root/reference/circuits/artifacts.go:401): with DVN_LOAD_KEY_FILES=1 the library reads the
+// same sha256-named file itself and keeps the device copy resident (prover.PreloadProvingKeyFile); a failure is logged by the
+// caller and ignored -- the first proof then imports the key from the decoded slices, as without the variable.
+func preloadDeviceKey(curve ecc.ID, ccs constraint.ConstraintSystem, pk groth16.ProvingKey, path, sha256hex string) error {
+	return preloadDeviceKeyImpl(curve, ccs, pk, path, sha256hex)
+}

@@ -32,3 +32,6 @@ func newProvingKey(curve ecc.ID) groth16.ProvingKey {
 func newVerifyingKey(curve ecc.ID) groth16.VerifyingKey {
 	return pick(curve, gpugroth16.NewVerifyingKey, groth16.NewVerifyingKey)
 }
+
+// preloadDeviceKey: the hip build's optional file preload (artifacts_hip.go) has no counterpart under the icicle tag.
+func preloadDeviceKey(ecc.ID, constraint.ConstraintSystem, groth16.ProvingKey, string, string) error { return nil }

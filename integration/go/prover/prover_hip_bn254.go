@@ -143,6 +143,7 @@ func importKeyBN254(ctx *C.dvn_ctx, r1cs *cs.R1CS, pk *groth16_bn254.ProvingKey)
 		sub := C.dvn_ctx_device(ctx, C.int32_t(i))
 		var h *C.dvn_groth16_pk
 		if err := hipCall(sub, func() C.int32_t { return C.dvn_groth16_pk_import(sub, &ka, &h) }); err != nil {
+			d.release(ctx) // the keys already resident on the earlier devices would otherwise stay in HBM for good
 			return nil, fmt.Errorf("dvn_groth16_pk_import (device %d): %w", i, err)
 		}
 		d.keys = append(d.keys, h)
@@ -153,17 +154,36 @@ func importKeyBN254(ctx *C.dvn_ctx, r1cs *cs.R1CS, pk *groth16_bn254.ProvingKey)
 		if err := hipCall(ctx, func() C.int32_t {
 			return C.dvn_points_upload_g1(ctx, g1PtrBN254(ck.Basis), C.size_t(len(ck.Basis)), &b)
 		}); err != nil {
+			d.release(ctx)
 			return nil, err
 		}
+		d.basis = append(d.basis, b)
 		if err := hipCall(ctx, func() C.int32_t {
 			return C.dvn_points_upload_g1(ctx, g1PtrBN254(ck.BasisExpSigma), C.size_t(len(ck.BasisExpSigma)), &s)
 		}); err != nil {
+			d.release(ctx)
 			return nil, err
 		}
-		d.basis, d.basisSig = append(d.basis, b), append(d.basisSig, s)
+		d.basisSig = append(d.basisSig, s)
 	}
 	pkDevBN254[pk] = d
 	return d, nil
+}
+
+// release frees whatever of the key is resident: the per-device handles (each on its own sub-context) and the commitment
+// bases on device 0.  Used on the error paths of importKeyBN254; a successfully imported key lives as long as the process.
+func (d *deviceKeyBN254) release(ctx *C.dvn_ctx) {
+	for i, h := range d.keys {
+		if h != nil {
+			C.dvn_groth16_pk_free(C.dvn_ctx_device(ctx, C.int32_t(i)), h)
+		}
+	}
+	for _, p := range append(d.basis, d.basisSig...) {
+		if p != nil {
+			C.dvn_points_free(ctx, p)
+		}
+	}
+	d.keys, d.basis, d.basisSig = nil, nil, nil
 }
 
 // hipProveBN254 restates gnark's Prove step for step (backend/groth16/bn254/prove.go).
