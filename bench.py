@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 BYTES_PER_PAIR = 96            # 32 B scalar + 64 B affine point
 # secondary (integer-issue) roofline of the dominant kernel -- context only, the contract's roofline is the HBM one:
 MADS_PER_ADD = 1467            # v_mad_u64_u32 per XYZZ mixed addition in k_accumulate's loop body (counted in the ISA)
-MAD_PEAK_PER_S = 35.4e12       # chip-wide v_mad_u64_u32 lane-op/s: the highest rate tools/microbench measured (profiles/r01_instr_rate_microbench.txt;
-                               # tools/microbench/valu_rates.hip on other boxes: 28.7-30.5e12)
+# the chip-wide v_mad_u64_u32 rate the integer context divides by is measured IN THIS RUN (dvn_bench_mad_rate): it differs by
+# ~20 % between boxes (tools/microbench/valu_rates.hip: 28.7-35.4e12 lane-op/s)
 
 
 def pmc_traffic(log_n, world):
@@ -472,6 +472,59 @@ def main():
             _, want22 = orc.groth16_synthetic_expected(7, 1 << 22, 9, 3, rs[0], rs[1])
             extras["groth16_synthetic_2^22"]["trapdoor_identity"] = bool(all((p22[k] == want22[k]).all() for k in want22))
         ctx.free(dw); key.free(); cs.free()
+        # above 2^22 (the real statetransition constraint count is not known offline: the path is parametric up to 2^24):
+        # one G1 MSM over 2^24 points against the closed form, computeH on the 2^24 domain (against the C oracle when the
+        # checker legs are on), the synthetic proof at 2^23 and 2^24 constraints against the trapdoor identity
+        if args.log_n == 22:
+            n24 = 1 << 24
+            pts24 = ctx.synthetic_g1(0xDA71C1, n24)
+            d24 = ctx.synthetic_scalars(11, 0, n24)
+            tk, last, t0 = [], None, None
+            for i in range(3 + 6):
+                if i == 3:
+                    ctx.synchronize(); t0 = time.perf_counter()
+                tk.append(ctx.msm_g1_submit(pts24, d24, n=n24))
+                if len(tk) == 3:
+                    last = ctx.msm_g1_collect(tk.pop(0))
+            while tk:
+                last = ctx.msm_g1_collect(tk.pop(0))
+            dt = (time.perf_counter() - t0) / 6
+            hs = np.empty((n24, 4), dtype=np.uint64); ctx.d2h(hs, d24)
+            extras["msm_g1_2^24_uniform"] = {"ms_per_msm": round(dt * 1e3, 3), "Mscalar_per_s": round(n24 / dt / 1e6, 1), "table_bytes": 13 * n24 * 64,
+                                             "closed_form": bool((closed_form_msm(ctx, pts24, hs) == last).all())}
+            ctx.free(d24); pts24.free(); del hs
+            dom24 = ctx.domain(24)
+            from oracle import cpu as orc24                      # input generator + (optional) checker: test infrastructure
+            ha, hb, hc = orc24.scalars(3, 0, n24), orc24.scalars(4, 0, n24), orc24.scalars(5, 0, n24)
+            da, db, dc = ctx.to_device(ha), ctx.to_device(hb), ctx.to_device(hc)
+            dh = ctx.malloc(n24 * 32)
+            hms = []
+            for _ in range(4):
+                ctx.compute_h_device(dom24, da, db, dc, n24, dh); hms.append(ctx.last_kernel_ms(0))
+            hmed = float(np.median(hms[1:]))
+            extras["compute_h_2^24"] = {"ms": round(hmed, 3), "algorithmic_GBps": round((7 * 64 + 4 * 32) * n24 / (hmed * 1e-3) / 1e9, 1),
+                                        "what": "7 transforms + the pointwise pass on three resident vectors, device time"}
+            if checker:
+                got = np.empty_like(ha); ctx.d2h(got, dh)
+                extras["compute_h_2^24"]["equals_cpu_oracle"] = bool((got == orc24.compute_h(ha, hb, hc, 24, orc24.usable_cores())).all())
+                del got
+            ctx.free(dh)
+            ctx.free(da); ctx.free(db); ctx.free(dc); dom24.free(); del ha, hb, hc
+            for ln in (23, 24):
+                cs = pkg.R1CS(7, 1 << ln, 9)
+                key = pkg.Groth16Key(ctx, cs, 3)
+                dw = ctx.to_device(cs.witness())
+                rs = np.zeros((2, 4), dtype=np.uint64); rs[0, 0], rs[1, 0] = 5, 7
+                pbig = key.prove(dw, rs[0], rs[1])
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    key.prove(dw, rs[0], rs[1])
+                dtp = (time.perf_counter() - t0) / 3
+                extras[f"groth16_synthetic_2^{ln}"] = {"post_solver_proofs_per_s": round(1 / dtp, 3), "ms_per_proof": round(dtp * 1e3, 3), "key_sizes": key.sizes}
+                if checker:
+                    _, wantb = orc24.groth16_synthetic_expected(7, 1 << ln, 9, 3, rs[0], rs[1])
+                    extras[f"groth16_synthetic_2^{ln}"]["trapdoor_identity"] = bool(all((pbig[k] == wantb[k]).all() for k in wantb))
+                ctx.free(dw); key.free(); cs.free()
         # CPU comparator for the proof metric (rank 0, bounded: one proof's worth of primitives): the oracle's own C Pippenger /
         # NTT (NOT gnark) on the same sizes as the BN254 key above -- four G1 MSMs, one G2 MSM, computeH at n = 2^20 -- on the
         # threads this box allows.  Points are synthetic (MSM cost does not depend on which points).
@@ -538,6 +591,7 @@ def main():
             ks.close()
 
     if rank == 0:
+        mad_peak = ctx.mad_rate()
         ms_per_step = elapsed / args.steps * 1e3
         value = n * args.steps / elapsed / 1e6
         pairs_per_launch = n // world                # the (scalar, point) pairs ONE launch of this rank's k_accumulate stands for: with the
@@ -569,8 +623,10 @@ def main():
                                                "mixed_additions_per_launch": adds_per_launch,
                                                "mad_per_addition": MADS_PER_ADD,
                                                "achieved_Tmad_per_s": round(adds_per_launch * MADS_PER_ADD / (acc * 1e-3) / 1e12, 2),
-                                               "measured_peak_Tmad_per_s": MAD_PEAK_PER_S / 1e12,
-                                               "frac": round(adds_per_launch * MADS_PER_ADD / (acc * 1e-3) / MAD_PEAK_PER_S, 4)}},
+                                               "measured_peak_Tmad_per_s": round(mad_peak / 1e12, 2),
+                                               "peak_source": "dvn_bench_mad_rate: every SIMD saturated with multiply-add chains, measured in this run on this device",
+                                               "frac": round(adds_per_launch * MADS_PER_ADD / (acc * 1e-3) / mad_peak, 4),
+                                               "frac_solo": round(adds_per_launch * MADS_PER_ADD / (honesty["kernel_ms_solo"] * 1e-3) / mad_peak, 4) if honesty and "kernel_ms_solo" in honesty else None}},
             "cpu_baseline": cpu,
             "extras": extras,
         }

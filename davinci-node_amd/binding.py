@@ -50,6 +50,7 @@ def load_library():
         "dvn_last_error": (C.c_char_p, [vp]),
         "dvn_version": (C.c_char_p, []),
         "dvn_test_raise": (i32, [i32]),
+        "dvn_bench_mad_rate": (i32, [vp, C.POINTER(C.c_double)]),
         "dvn_malloc": (i32, [vp, sz, C.POINTER(vp)]),
         "dvn_free": (i32, [vp, vp]),
         "dvn_memcpy_h2d": (i32, [vp, vp, vp, sz]),
@@ -206,7 +207,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = [
-    "dvn_init", "dvn_shutdown", "dvn_last_error", "dvn_version", "dvn_test_raise", "dvn_malloc", "dvn_free", "dvn_memcpy_h2d",
+    "dvn_init", "dvn_shutdown", "dvn_last_error", "dvn_version", "dvn_test_raise", "dvn_bench_mad_rate", "dvn_malloc", "dvn_free", "dvn_memcpy_h2d",
     "dvn_memcpy_d2h", "dvn_synchronize", "dvn_points_upload_g1", "dvn_points_upload_g2", "dvn_points_synthetic_g1",
     "dvn_points_synthetic_g2", "dvn_scalars_synthetic", "dvn_points_set_expanded", "dvn_points_download", "dvn_points_len", "dvn_points_free", "dvn_msm_g1", "dvn_msm_g1_static", "dvn_msm_g2", "dvn_msm_g1_batched",
     "dvn_msm_g1_submit", "dvn_msm_g1_collect", "dvn_msm_g2_submit", "dvn_msm_g2_collect", "dvn_msm_plan", "dvn_msm_plan_points", "dvn_msm_g1_windows", "dvn_msm_g1_windows_submit", "dvn_msm_g1_windows_collect", "dvn_msm_combine_g1", "dvn_ntt_domain", "dvn_ntt_domain_free", "dvn_ntt",
@@ -500,12 +501,24 @@ class Context:
         self._chk(self.L.dvn_groth16_compute_h(self.h, dom.handle, _host(a), _host(b), _host(c), a.shape[0], _host(out), 0))
         return out
 
+    def compute_h_device(self, dom: Domain, da: int, db: int, dc: int, length: int, dout: int):
+        """computeH on device-resident a, b, c (`length` elements each, left untouched) into the device buffer dout (dom.n
+        elements); last_kernel_ms(0) is the device time of the seven transforms and the pointwise pass."""
+        vp = C.c_void_p
+        self._chk(self.L.dvn_groth16_compute_h(self.h, dom.handle, vp(da), vp(db), vp(dc), length, vp(dout), 1))
+
     def pedersen_commit(self, basis: Points, basis_exp_sigma: Points, values: np.ndarray):
         """(commitment, pok) G1Affine images: MSM(Basis, values), MSM(BasisExpSigma, values)."""
         values = np.ascontiguousarray(values, dtype=np.uint64).reshape(-1, 4)
         c, k = np.zeros(8, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
         self._chk(self.L.dvn_pedersen_commit(self.h, basis.handle, basis_exp_sigma.handle, _host(values), values.shape[0], 0, _host(c), _host(k)))
         return c, k
+
+    def mad_rate(self) -> float:
+        """Chip-wide v_mad_u64_u32 lane operations per second of this device, measured now (dvn_bench_mad_rate)."""
+        v = C.c_double()
+        self._chk(self.L.dvn_bench_mad_rate(self.h, C.byref(v)))
+        return float(v.value)
 
     def last_kernel_ms(self, which: int = 0) -> float:
         ms = C.c_float(); self._chk(self.L.dvn_last_kernel_ms(self.h, which, C.byref(ms))); return float(ms.value)

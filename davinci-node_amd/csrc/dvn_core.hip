@@ -172,3 +172,54 @@ extern "C" int32_t dvn_last_kernel_ms(dvn_ctx* ctx, int which, float* ms) try {
     return DVN_OK;
 } DVN_CATCH
 
+
+
+// ------------------------------------------------------------------------------------------------------
+// Bench-only: this GPU's v_mad_u64_u32 issue rate, measured in the run that quotes it.
+// The hot kernels of the library (bucket accumulation, NTT butterflies) are bound by the issue of this one instruction; their
+// "fraction of the integer peak" is only meaningful against the rate of the box they ran on (it differs by ~20 % between
+// boxes and with clocks).  Every SIMD is saturated (8 waves each) with 8 independent multiply-add chains per lane; the rate
+// is taken from the difference of a long and a short launch, so launch overhead cancels.
+// ------------------------------------------------------------------------------------------------------
+static __global__ __launch_bounds__(256) void k_mad_chain(u64* __restrict__ out, u32 seed, int rounds) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    u64 a[8]; u32 w[8];
+    u32 m = seed * 2654435761u + t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = t + i; w[i] = t + 7 * i + 1; }
+    for (int it = 0; it < 2048 * rounds; ++it) {
+        asm volatile("" : "+v"(m));                    // opaque: the recurrence has no closed form for the compiler
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(a[i]) : "v"(w[i]), "v"(m) : "vcc");
+    }
+    u64 r = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r += a[i];
+    out[t] = r;
+}
+extern "C" int32_t dvn_bench_mad_rate(dvn_ctx* ctx, double* lane_ops_per_s) try {
+    TRY(enter(ctx));
+    if (!lane_ops_per_s) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+    const int blocks = prop.multiProcessorCount * 8;           // 8 blocks of 4 waves per CU: 8 waves per SIMD
+    u64* out = nullptr;
+    HIP_TRY(hipMalloc((void**)&out, (size_t)blocks * 256 * 8));
+    float ms[2] = {0.f, 0.f};
+    hipError_t e = hipSuccess;
+    for (int r = 0; r < 2 && e == hipSuccess; ++r) {
+        const int rounds = r ? 9 : 1;
+        k_mad_chain<<<blocks, 256, 0, ctx->stream>>>(out, 1, rounds);            // warm
+        e = hipEventRecord(ctx->ev[0], ctx->stream);
+        k_mad_chain<<<blocks, 256, 0, ctx->stream>>>(out, 2, rounds);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev[1], ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms[r], ctx->ev[0], ctx->ev[1]);
+    }
+    (void)hipFree(out);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(DVN_ERR_DEVICE, "mad-rate probe failed: %s", hipGetErrorString(e)); }
+    const double lane_ops = (double)blocks * 256.0 * 2048.0 * 8.0 /* rounds difference */ * 8.0 /* chains */;
+    *lane_ops_per_s = lane_ops / ((double)(ms[1] - ms[0]) * 1e-3);
+    return DVN_OK;
+} DVN_CATCH

@@ -61,6 +61,10 @@ const char* dvn_version(void);
  * exception-to-code mapping of the boundary can be checked.  0 none (DVN_OK), 1 std::bad_alloc, 2 std::system_error (both
  * DVN_ERR_OOM), 3 std::runtime_error, 4 a non-standard exception (both DVN_ERR_DEVICE).  No counterpart in the reference. */
 int32_t dvn_test_raise(int32_t kind);
+/* Bench only, no counterpart in the reference: the chip-wide v_mad_u64_u32 issue rate of THIS device right now, in lane
+ * operations per second (every SIMD saturated with independent multiply-add chains; ~10 ms).  The hot kernels are bound by
+ * the issue of that instruction, so bench.py quotes their integer-issue fraction against this in-run figure. */
+int32_t dvn_bench_mad_rate(dvn_ctx* ctx, double* lane_ops_per_s);
 
 /* ---- device memory helpers (bench/test harness; also used by the host orchestration) ------------------ */
 int32_t dvn_malloc(dvn_ctx* ctx, size_t bytes, void** dptr);

@@ -162,3 +162,97 @@ def test_plonk_shaped_composition_results(ctx, pkg):
     x1 = np.empty_like(x0); ctx.d2h(x1, dx)
     assert (x0 == x1).all()
     ctx.free(dx); ctx.free(vecs[0]); dom.free(); dom22.free()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Above 2^22.  The statetransition circuit's real constraint count is not known offline (its artifacts are CDN-hosted), so the
+# path is parametric in log2 n up to 24: these run the same checks at the top of that range.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("log_n", [22, 24])
+def test_compute_h_2p22_2p24_vs_oracle(ctx, orc, log_n):
+    """computeH (7 transforms + the pointwise pass, a / b / c resident) at 2^22 and 2^24 against the C oracle, bit for bit, with
+    ragged input lengths (the domain zero-pads)."""
+    m = (1 << log_n) - 5
+    dom = ctx.domain(log_n)
+    a, b, c = orc.scalars(3, 0, m), orc.scalars(4, 0, m), orc.scalars(5, 0, m)
+    got = ctx.compute_h(dom, a, b, c)
+    want = orc.compute_h(a, b, c, log_n, orc.usable_cores())
+    assert (got == want).all()
+    dom.free()
+
+
+def _closed_form(ctx, pts, dscal, n):
+    """sum s_i (P0 + i D) = (S0 - S1) P0 + S1 P1 over the arithmetic-progression point set, as a 2-point MSM."""
+    sm = np.empty((n, 4), dtype=np.uint64); ctx.d2h(sm, dscal)
+    idx = np.arange(n, dtype=np.uint64)
+    s0 = s1 = 0
+    for limb in range(4):
+        for piece in range(4):                                   # 16-bit digit planes keep every partial sum below 2^64
+            d = (sm[:, limb] >> np.uint64(16 * piece)) & np.uint64(0xFFFF)
+            sh = 64 * limb + 16 * piece
+            s0 += int(d.sum(dtype=np.uint64)) << sh
+            s1 += int(np.dot(idx, d)) << sh
+    rinv = pow(1 << 256, -1, R)
+    S0, S1 = s0 * rinv % R, s1 * rinv % R
+    to_m = lambda x: [((x << 256) % R >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)]
+    two = ctx.upload_g1(pts.download(0, 2))
+    out = ctx.msm_g1(two, np.array([to_m((S0 - S1) % R), to_m(S1)], dtype=np.uint64))
+    two.free()
+    return out
+
+
+def test_msm_g1_2p24_closed_form(ctx, pkg):
+    """One G1 MSM over 2^24 points (a 14 GB table of 13 rows; 2^27.7 sorted entries) against the closed form, uniform and
+    witness-like scalars, and three in flight."""
+    n = 1 << 24
+    pts = ctx.synthetic_g1(0xDA71C1, n)
+    c, nwin, combine = ctx.msm_plan_points(pts, n)
+    assert combine == 0 and c == 20 and nwin == 13
+    for kind in (0, 1):
+        d = ctx.synthetic_scalars(7 + kind, kind, n)
+        want = _closed_form(ctx, pts, d, n)
+        assert (ctx.msm_g1(pts, d, n=n) == want).all(), kind
+        if kind == 0:
+            tk = [ctx.msm_g1_submit(pts, d, n=n) for _ in range(3)]
+            assert all((ctx.msm_g1_collect(t) == want).all() for t in tk)
+        ctx.free(d)
+    pts.free()
+
+
+@pytest.mark.parametrize("log_n", [23, 24])
+def test_groth16_2p23_2p24_trapdoor_identity(ctx, pkg, opy, orc, log_n):
+    """The synthetic statetransition-shaped proof at 2^23 and 2^24 constraints (key sets of that many points as 13-row tables,
+    computeH on that domain) against the trapdoor closed form."""
+    n_c = 1 << log_n
+    cs = pkg.R1CS(7, n_c, 9)
+    key = pkg.Groth16Key(ctx, cs, 3)
+    assert key.log_n == log_n
+    r, s = mont(opy, 5), mont(opy, 7)
+    dw = ctx.to_device(cs.witness())
+    got = key.prove(dw, r, s)
+    _, want = orc.groth16_synthetic_expected(7, n_c, 9, 3, r, s)
+    for k in ("Ar", "Bs", "Krs"):
+        assert (got[k] == want[k]).all(), k
+    ctx.free(dw); key.free(); cs.free()
+
+
+def test_sizes_beyond_31_bit_entry_positions_are_refused(ctx, pkg):
+    """Entry positions and point references are 31-bit: a set whose table would need more rows x points than that stays plain,
+    an MSM whose windows x n does not fit is refused with DVN_ERR_INVALID_ARG (a message that names the limit), and the
+    context keeps working."""
+    n = 1 << 28                                                  # 16 GiB of points: fits HBM, 16 windows x 2^28 entries do not fit 31 bits
+    pts = ctx.synthetic_g1(3, n)
+    c, nwin, combine = ctx.msm_plan_points(pts, n)
+    assert combine != 0                                           # left plain: 13 rows x 2^28 references would overflow
+    d = ctx.synthetic_scalars(1, 0, 1 << 20)
+    big = ctx.synthetic_scalars(2, 1, n)
+    with pytest.raises(pkg.DvnError) as e:
+        ctx.msm_g1_submit(pts, big, n=n)
+    assert e.value.code == -1 and "31-bit" in str(e.value)
+    ctx.free(big)
+    with pytest.raises(pkg.DvnError) as e:
+        pts.set_expanded(20)
+    assert e.value.code == -1 and "too large" in str(e.value)
+    # a 2^20 slice of the same set still runs (plain path), and equals the closed form
+    assert (ctx.msm_g1(pts, d, n=1 << 20) == _closed_form(ctx, pts, d, 1 << 20)).all()
+    ctx.free(d); pts.free()
