@@ -40,12 +40,12 @@ def pmc_traffic(log_n, world):
     """HBM bytes per k_accumulate launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
     separate runs of tools/prof_collect.sh, KiB -> bytes; raw counter values: the kernel reads 64-byte gathers, not the wide
     streams the guide's x2 FETCH_SIZE correction was calibrated on).  Only valid for the workload it was collected on."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_msm_g1_2p22_per_kernel_v2_final.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_msm_g1_2p22_per_kernel.json")
     if log_n != 22 or world != 1 or not os.path.exists(path):
         return None, None
     try:
         k = [v for name, v in json.load(open(path)).items() if "k_accumulate" in name][0]
-        return round((k["FETCH_SIZE"]["max"] + k["WRITE_SIZE"]["max"]) * 1024 / 1e9, 3), "GB per launch, profiles/r02_pmc_msm_g1_2p22_per_kernel_v2_final.json"
+        return round((k["FETCH_SIZE"]["max"] + k["WRITE_SIZE"]["max"]) * 1024 / 1e9, 3), "GB per launch, profiles/r03_pmc_msm_g1_2p22_per_kernel.json"
     except Exception:
         return None, None
 
