@@ -89,14 +89,16 @@ static inline void expand_plan(size_t n, u32 scalar_bits, size_t point_bytes, u3
 struct dvn_domain {
     int suite = 0;            // 0 = BN254 Fr, 1 = BLS12-377 Fr
     u32 log_n = 0;
-    u32* tw_fwd = nullptr;    // per-stage tables, n-1 entries (8 words each), entry (n - (n>>s)) + k = w^(k<<s)
+    u32* tw_fwd = nullptr;    // per-stage tables, n-1 entries of NL limbs in planes, entry (n - (n>>s)) + k = w^(k<<s)
     u32* tw_inv = nullptr;
+    u32* tw_fwd_c = nullptr;  // the same with stage s scaled by g^(2^s): the DIT network evaluates on the coset g<w>
+    u32* tw_inv_c = nullptr;  // w^-1 and g^-(2^s): the DIF network returns the inverse coset transform (times n)
     // coset power tables (exponent split lo/hi), internal form
     u32 lo_bits = 0;
     u32 *g_lo = nullptr, *g_hi = nullptr;            // g^j, g^(j<<lo_bits)
     u32 *gi_lo = nullptr, *gi_hi = nullptr;          // g^-j / n, g^-(j<<lo_bits)
     u32* card_inv = nullptr;                         // 1/n (one element)
-    u32* h_consts = nullptr;                         // k1 = den*2^5, k2 = den (computeH)
+    u32* h_consts = nullptr;                         // computeH: k1 = den * 2^5 / n^3, k2 = den / n^2
 };
 
 int32_t fail(int32_t code, const char* fmt, ...);

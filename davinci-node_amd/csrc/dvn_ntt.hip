@@ -6,9 +6,7 @@ extern "C" int32_t dvn_ntt_domain_free(dvn_ctx* ctx, dvn_domain* d) try {
     if (!d) return DVN_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
     (void)hipStreamSynchronize(ctx->stream);
-    u32* ptrs[] = {d->tw_fwd, d->tw_inv, d->g_lo, d->g_hi, d->gi_lo, d->gi_hi, d->card_inv, d->h_consts};
-    for (u32* p : ptrs) if (p) (void)hipFree(p);
-    delete d;
+    ntt_domain_release(d);
     return DVN_OK;
 } DVN_CATCH
 extern "C" int32_t dvn_ntt_domain(dvn_ctx* ctx, uint32_t log_n, dvn_domain** out) try { return ntt_domain_create<FrCfg>(ctx, log_n, out); } DVN_CATCH

@@ -296,12 +296,7 @@ static int32_t kzg_points_from_compressed(dvn_ctx* ctx, dvn_kzg_setup* s, const 
 static void kzg_setup_destroy(dvn_kzg_setup* s) {            // no locking, no ctx: direct frees (caller synchronised)
     if (!s) return;
     for (dvn_points* p : {s->lagrange_brp, s->monomial}) if (p) { if (p->d) (void)hipFree(p->d); delete p; }
-    if (s->dom) {
-        dvn_domain* d = s->dom;
-        u32* ptrs[] = {d->tw_fwd, d->tw_inv, d->g_lo, d->g_hi, d->gi_lo, d->gi_hi, d->card_inv, d->h_consts};
-        for (u32* q : ptrs) if (q) (void)hipFree(q);
-        delete d;
-    }
+    ntt_domain_release(s->dom);
     void* bufs[] = {s->d_bytes, s->d_f, s->d_q, s->d_cellq, s->d_res, s->d_small, s->d_inv, s->d_g, s->tab_lagrange, s->tab_monomial};
     for (void* b : bufs) if (b) (void)hipFree(b);
     delete s;

@@ -48,6 +48,24 @@ template <class S> static int32_t launch_powers(dvn_ctx* ctx, u32* d_out, const 
     HIP_TRY(hipStreamSynchronize(ctx->stream));   // h goes out of scope
     return DVN_OK;
 }
+// entries [e0, e0 + count) of a twiddle table of n_entries entries in limb planes: first * base^k
+template <class S> static int32_t launch_powers_planes(dvn_ctx* ctx, u32* d_table, u32 n_entries, u32 e0, const Fe<S>& base, const Fe<S>& first, size_t count, u32* d_scratch16) {
+    u32 h[2 * S::EW]; fr_store_internal<S>(base, h); fr_store_internal<S>(first, h + S::EW);
+    HIP_TRY(hipMemcpyAsync(d_scratch16, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+    const u32 chunk = 64;
+    size_t threads = (count + chunk - 1) / chunk;
+    k_powers_planes<S><<<(unsigned)((threads + 63) / 64), 64, 0, ctx->stream>>>(d_table, n_entries, e0, d_scratch16, count, chunk);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return DVN_OK;
+}
+
+static inline void ntt_domain_release(dvn_domain* d) {            // no locking, no ctx: direct frees (caller synchronised)
+    if (!d) return;
+    u32* ptrs[] = {d->tw_fwd, d->tw_inv, d->tw_fwd_c, d->tw_inv_c, d->g_lo, d->g_hi, d->gi_lo, d->gi_hi, d->card_inv, d->h_consts};
+    for (u32* p : ptrs) if (p) (void)hipFree(p);
+    delete d;
+}
 
 template <class S> static int32_t ntt_domain_create(dvn_ctx* ctx, uint32_t log_n, dvn_domain** out) {
     TRY(enter(ctx));
@@ -63,21 +81,27 @@ template <class S> static int32_t ntt_domain_create(dvn_ctx* ctx, uint32_t log_n
     u32* scratch = nullptr;
     int32_t rc = DVN_OK;
     auto alloc = [&](u32** p, size_t entries) -> int32_t { HIP_TRY(hipMalloc((void**)p, entries * S::EW * 4)); return DVN_OK; };
+    // a twiddle table: n entries of NL limbs in planes (entry n - 1 is never written or read)
+    auto alloc_tw = [&](u32** p) -> int32_t { HIP_TRY(hipMalloc((void**)p, n * S::NL * 4)); HIP_TRY(hipMemsetAsync(*p, 0, n * S::NL * 4, ctx->stream)); return DVN_OK; };
     do {
-        if ((rc = alloc(&d->tw_fwd, n)) || (rc = alloc(&d->tw_inv, n)) || (rc = alloc(&d->g_lo, nlo)) || (rc = alloc(&d->g_hi, nhi)) ||
+        if ((rc = alloc_tw(&d->tw_fwd)) || (rc = alloc_tw(&d->tw_inv)) || (rc = alloc_tw(&d->tw_fwd_c)) || (rc = alloc_tw(&d->tw_inv_c)) ||
+            (rc = alloc(&d->g_lo, nlo)) || (rc = alloc(&d->g_hi, nhi)) ||
             (rc = alloc(&d->gi_lo, nlo)) || (rc = alloc(&d->gi_hi, nhi)) || (rc = alloc(&d->card_inv, 1)) || (rc = alloc(&d->h_consts, 2)) ||
             (rc = alloc(&scratch, 2))) break;
         const Fe<S> one = fe_one<S>();
         const Fe<S> w = fr_root_of_unity<S>(log_n), wi = fe_inv<S>(w);
-        Fe<S> ws = w, wis = wi;
+        const Fe<S> g = fr_from_u64<S>(DomainConsts<S>::COSET_GEN), gi = fe_inv<S>(g), ninv = fe_inv<S>(fr_from_u64<S>(n));
+        Fe<S> ws = w, wis = wi, gs = g, gis = gi;               // w^(2^s), w^-(2^s), g^(2^s), g^-(2^s)
         for (u32 s = 0; s < log_n && rc == DVN_OK; ++s) {
-            const size_t half = n >> (s + 1), offs = n - (n >> s);
-            if ((rc = launch_powers<S>(ctx, d->tw_fwd + offs * S::EW, ws, one, half, scratch))) break;
-            if ((rc = launch_powers<S>(ctx, d->tw_inv + offs * S::EW, wis, one, half, scratch))) break;
-            ws = fe_sqr<S>(ws); wis = fe_sqr<S>(wis);
+            const size_t half = n >> (s + 1);
+            const u32 offs = (u32)(n - (n >> s));
+            if ((rc = launch_powers_planes<S>(ctx, d->tw_fwd, (u32)n, offs, ws, one, half, scratch))) break;
+            if ((rc = launch_powers_planes<S>(ctx, d->tw_inv, (u32)n, offs, wis, one, half, scratch))) break;
+            if ((rc = launch_powers_planes<S>(ctx, d->tw_fwd_c, (u32)n, offs, ws, gs, half, scratch))) break;
+            if ((rc = launch_powers_planes<S>(ctx, d->tw_inv_c, (u32)n, offs, wis, gis, half, scratch))) break;
+            ws = fe_sqr<S>(ws); wis = fe_sqr<S>(wis); gs = fe_sqr<S>(gs); gis = fe_sqr<S>(gis);
         }
         if (rc) break;
-        const Fe<S> g = fr_from_u64<S>(DomainConsts<S>::COSET_GEN), gi = fe_inv<S>(g), ninv = fe_inv<S>(fr_from_u64<S>(n));
         if ((rc = launch_powers<S>(ctx, d->g_lo, g, one, nlo, scratch))) break;
         if ((rc = launch_powers<S>(ctx, d->g_hi, fe_pow_u64<S>(g, nlo), one, nhi, scratch))) break;
         if ((rc = launch_powers<S>(ctx, d->gi_lo, gi, ninv, nlo, scratch))) break;
@@ -85,10 +109,13 @@ template <class S> static int32_t ntt_domain_create(dvn_ctx* ctx, uint32_t log_n
         constexpr u32 EW = S::EW;
         u32 h[3 * EW];
         fr_store_internal<S>(ninv, h);
-        // den = 1/(g^n - 1); k1 = den * 2^5 (internal), k2 = den
+        // computeH runs its seven transforms without any 1/n: the pointwise constants carry them.  With A', B', C' the unscaled
+        // coset evaluations (n times the true ones) and the last inverse unscaled as well, h = raw[A' B' den / n^3 - C' den / n^2].
+        // k1 = den * 2^EXT_SHIFT / n^3 (the product of two external words is read 2^-EXT_SHIFT too small), k2 = den / n^2
         const Fe<S> den = fe_inv<S>(fe_sub<S>(fe_pow_u64<S>(g, n), one));
-        fr_store_internal<S>(fe_mul<S>(den, fr_from_u64<S>(1u << S::EXT_SHIFT)), h + EW);
-        fr_store_internal<S>(den, h + 2 * EW);
+        const Fe<S> ninv2 = fe_sqr<S>(ninv);
+        fr_store_internal<S>(fe_mul<S>(fe_mul<S>(den, fr_from_u64<S>(1u << S::EXT_SHIFT)), fe_mul<S>(ninv2, ninv)), h + EW);
+        fr_store_internal<S>(fe_mul<S>(den, ninv2), h + 2 * EW);
         hipError_t e = hipMemcpy(d->card_inv, h, EW * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(d->h_consts, h + EW, 2 * EW * 4, hipMemcpyHostToDevice);
         if (e != hipSuccess) { (void)hipGetLastError(); rc = fail(DVN_ERR_DEVICE, "domain constant upload failed: %s", hipGetErrorString(e)); }
@@ -96,9 +123,7 @@ template <class S> static int32_t ntt_domain_create(dvn_ctx* ctx, uint32_t log_n
     if (scratch) (void)hipFree(scratch);
     if (rc != DVN_OK) {
         std::string keep = tl_error;
-        u32* ptrs[] = {d->tw_fwd, d->tw_inv, d->g_lo, d->g_hi, d->gi_lo, d->gi_hi, d->card_inv, d->h_consts};
-        for (u32* p : ptrs) if (p) (void)hipFree(p);
-        delete d;
+        ntt_domain_release(d);
         tl_error = keep;
         return rc;
     }
@@ -119,20 +144,41 @@ template <class S> static int32_t ntt_attrs(int device) {
     }
     return DVN_OK;
 }
+// what computeH asks of a transform beyond the public modes
+struct NttOpt {
+    bool no_ninv = false;                              // inverse transforms: leave the 1/n out
+    const u32* hb = nullptr; const u32* hc = nullptr;  // first pass loads data[i] * hb[i] * k1 - hc[i] * k2 (k1, k2 = the domain's h_consts)
+};
+// passes of up to NTT_KMAX stages: tiles of 2^K sub-problem elements times I neighbours (>= 64-byte runs in HBM)
+constexpr u32 NTT_KMAX = 10;
 // in-place transform of device data; asynchronous on ctx->stream
-template <class S> static int32_t ntt_device(dvn_ctx* ctx, const dvn_domain* d, u32* data, int inverse, int decimation, int coset) {
+template <class S> static int32_t ntt_device(dvn_ctx* ctx, const dvn_domain* d, u32* data, int inverse, int decimation, int coset, const NttOpt& opt = NttOpt()) {
     RoctxRange rr(inverse ? "dvn:ntt_inverse" : "dvn:ntt_forward");
     const u32 log_n = d->log_n;
-    const u32 npass = (log_n + 7) / 8;
+    static const u32 kmax = [] { const char* e = getenv("DVN_NTT_KMAX"); const int v = e ? atoi(e) : 0; return (u32)(v >= 2 && v <= 11 ? v : NTT_KMAX); }();
+    const u32 npass = (log_n + kmax - 1) / kmax;
     const u32 base = log_n / npass, rem = log_n % npass;
-    u32 ks[8];
+    // stage counts per pass in execution order.  The pass that holds the transform's last two stages (the last pass of DIF, the
+    // first of DIT) gets an even count when there is a choice, so that those two stages form one radix-4 round.
+    u32 ks[16];
     for (u32 p = 0; p < npass; ++p) ks[p] = base + (p < rem ? 1 : 0);
-    const u32* tw = inverse ? d->tw_inv : d->tw_fwd;
-    NttScale none{nullptr, nullptr, 0, 0, 0, 0};
+    if (npass > 1) {
+        const u32 end = decimation == DVN_DIF ? npass - 1 : 0;
+        if (ks[end] & 1) {
+            // swap with a pass of even count, if any
+            for (u32 p = 0; p < npass; ++p) if (!(ks[p] & 1)) { const u32 t = ks[p]; ks[p] = ks[end]; ks[end] = t; break; }
+        }
+    }
+    // the butterfly network absorbs the coset scaling where its shape allows (DIT: a scaling of the input, DIF: of the output)
+    const bool merged = coset && ((!inverse && decimation == DVN_DIT) || (inverse && decimation == DVN_DIF));
+    const u32* tw = inverse ? (merged ? d->tw_inv_c : d->tw_inv) : (merged ? d->tw_fwd_c : d->tw_fwd);
+    NttScale none{nullptr, nullptr, 0, 0, 0, 0, nullptr};
     NttScale sc = none;
-    if (!inverse && coset) sc = NttScale{d->g_lo, d->g_hi, d->lo_bits, 2, decimation == DVN_DIT, 1};
-    if (inverse && !coset) sc = NttScale{d->card_inv, nullptr, 0, 1, 0, 2};
-    if (inverse && coset) sc = NttScale{d->gi_lo, d->gi_hi, d->lo_bits, 2, decimation == DVN_DIF, 2};
+    if (!inverse && coset && !merged) sc = NttScale{d->g_lo, d->g_hi, d->lo_bits, 2, 0, 1, nullptr};                 // DIF: g^i at load
+    if (inverse && (!coset || merged) && !opt.no_ninv) sc = NttScale{d->card_inv, nullptr, 0, 1, 0, 2, nullptr};     // 1/n at store
+    if (inverse && coset && !merged) sc = NttScale{d->gi_lo, d->gi_hi, d->lo_bits, 2, 0, 2, nullptr};                // DIT: g^-i / n at store
+    NttScale pointwise{opt.hb, opt.hc, 0, 3, 0, 1, d->h_consts};
+    if (opt.hb && (sc.mode && sc.when == 1)) return fail(DVN_ERR_INVALID_ARG, "internal: pointwise load on a pre-scaled transform");
     // stage ranges in execution order
     for (u32 p = 0; p < npass; ++p) {
         u32 sa, sb;
@@ -143,28 +189,32 @@ template <class S> static int32_t ntt_device(dvn_ctx* ctx, const dvn_domain* d, 
         while (K + log_i > log_n) --log_i;                 // tile must not exceed the array
         // an LDS slot is the element's NL limbs (ntt_kernels.h): tiles of 2048 nine-limb (72 KiB) / 1024 fourteen-limb (56 KiB)
         // elements, two blocks per CU
-        while (((size_t)1 << (K + log_i)) * S::NL * 4 > NTT_TILE_LDS_MAX) --log_i;
-        const u32 tiles = (u32)(((size_t)1 << log_n) >> (K + log_i));
+        while (log_i > 0 && ((size_t)1 << (K + log_i)) * S::NL * 4 > NTT_TILE_LDS_MAX) --log_i;
         const size_t lds = ((size_t)1 << (K + log_i)) * S::NL * 4;
+        if (lds > NTT_TILE_LDS_MAX) return fail(DVN_ERR_DEVICE, "internal: a pass of %u stages does not fit the LDS tile", K);
+        const u32 tiles = (u32)(((size_t)1 << log_n) >> (K + log_i));
         TRY(ntt_attrs<S>(ctx->device));
         NttScale use = none;
         if (sc.mode && ((sc.when == 1 && p == 0) || (sc.when == 2 && p == npass - 1))) use = sc;
-        k_ntt_pass<S><<<tiles, 512, lds, ctx->stream>>>(data, tw, log_n, sa, sb, decimation == DVN_DIT, p == npass - 1, log_i, use);
+        if (opt.hb && p == 0) use = pointwise;
+        const int triv = !merged && sb == log_n && K >= 2;
+        k_ntt_pass<S><<<tiles, 512, lds, ctx->stream>>>(data, tw, log_n, sa, sb, decimation == DVN_DIT, p == npass - 1, log_i, triv, use);
         HIP_TRY(hipGetLastError());
     }
     return DVN_OK;
 }
 
 // computeH core on device buffers (gnark prove.go computeH): 3 x FFTInverse(DIF), 3 x FFT(DIT, coset),
-// pointwise (a*b - c) * den, FFTInverse(DIF, coset).  Result in da, bit-reversed.  Caller holds ctx->mu.
+// pointwise (a*b - c) * den, FFTInverse(DIF, coset).  Result in da, bit-reversed; db and dc are left holding intermediate
+// values.  No transform scales: the 1/n factors live in the pointwise constants, the coset shifts in the twiddles, and the
+// pointwise step itself runs in the load of the last transform.  Caller holds ctx->mu.
 template <class S> static int32_t compute_h_device(dvn_ctx* ctx, const dvn_domain* dom, u32* da, u32* db, u32* dc) {
-    const size_t n = (size_t)1 << dom->log_n;
     u32* v[3] = {da, db, dc};
-    for (int i = 0; i < 3; ++i) TRY(ntt_device<S>(ctx, dom, v[i], 1, DVN_DIF, 0));
+    NttOpt raw; raw.no_ninv = true;
+    for (int i = 0; i < 3; ++i) TRY(ntt_device<S>(ctx, dom, v[i], 1, DVN_DIF, 0, raw));
     for (int i = 0; i < 3; ++i) TRY(ntt_device<S>(ctx, dom, v[i], 0, DVN_DIT, 1));
-    k_h_pointwise<S><<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(da, db, dc, dom->h_consts, n);
-    HIP_TRY(hipGetLastError());
-    TRY(ntt_device<S>(ctx, dom, da, 1, DVN_DIF, 1));
+    NttOpt fin; fin.no_ninv = true; fin.hb = db; fin.hc = dc;
+    TRY(ntt_device<S>(ctx, dom, da, 1, DVN_DIF, 1, fin));
     return DVN_OK;
 }
 // the C-ABI entry (host or device a, b, c of `len` <= n elements, zero-padded): shared by every scalar field

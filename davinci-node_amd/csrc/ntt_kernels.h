@@ -9,7 +9,12 @@
 // neighbouring sub-problems of 2^K elements, so every global access is a run of I * 32 B = 256 B and the
 // 2^K * I-element tile (2048 elements of nine limbs = 72 KiB of LDS) sees K stages for one HBM read + one HBM write.  Twiddles come from
 // per-stage tables table_s[k] = w^(k * 2^s) in HBM (contiguous in k, i.e. coalesced across a tile row); the
-// late, small tables stay in L2 / Infinity Cache.
+// late, small tables stay in L2 / Infinity Cache.  A table entry is stored as the NL 29-bit limbs the multiplier takes (limb
+// planes over the whole table, the layout of the LDS tile), not as packed words: no bit slicing per twiddle.
+//
+// Coset transforms need no scaling pass where the butterfly network can absorb it: a DIT network whose stage-s twiddles are
+// g^(2^s) * w^(k 2^s) evaluates on the coset g<w> directly (P(g x) = Pe(g^2 x^2) + g x Po(g^2 x^2)), and a DIF network with
+// g^-(2^s) * w^-(k 2^s) returns the inverse transform already multiplied by g^-j.  The domain holds those two extra table sets.
 //
 // Data words are gnark Montgomery words (x * 2^256), read as the internal form of x * 2^-5; the transform is
 // linear so no conversion pass is needed (bn254_field.h header).  Twiddles / scale factors are true internal
@@ -77,13 +82,24 @@ template <class S> __global__ void k_powers(u32* __restrict__ out, const u32* __
     for (size_t k = lo; k < hi; ++k) { st_fr<S>(cur, out + k * S::EW); cur = fe_mul<S>(cur, base); }
 }
 
+// the same progression written as limb planes: entry e0 + k of a table of E entries (lds_st layout), canonical limbs
+template <class S> __global__ void k_powers_planes(u32* __restrict__ out, u32 E, u32 e0, const u32* __restrict__ base_first, size_t count, u32 chunk) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t lo = t * chunk;
+    if (lo >= count) return;
+    size_t hi = lo + chunk < count ? lo + chunk : count;
+    Fe<S> base = ld_fr<S>(base_first), cur = fe_mul<S>(fe_pow_u64<S>(base, (u64)lo), ld_fr<S>(base_first + S::EW));
+    for (size_t k = lo; k < hi; ++k) { lds_st<S>(out, e0 + (u32)k, E, fe_canonical<S>(cur)); cur = fe_mul<S>(cur, base); }
+}
+
 struct NttScale {
     const u32* lo;     // lo[j]  = f^j * c,            j < 2^lo_bits   (mode 2); lo[0] = constant (mode 1)
     const u32* hi;     // hi[j]  = f^(j << lo_bits),   j < n >> lo_bits
     u32 lo_bits;
-    int mode;          // 0 none, 1 constant, 2 power table
+    int mode;          // 0 none, 1 constant, 2 power table, 3 (at load only) computeH's pointwise step: v = v * lo[i] * aux[0] - hi[i] * aux[1]
     int bitrev;        // exponent = bitrev(i) instead of i
     int when;          // 1 = at load (pre-scale), 2 = at store (post-scale)
+    const u32* aux;    // mode 3: the two constants (2 elements)
 };
 
 template <class S> __device__ __forceinline__ Fe<S> ntt_scale_factor(const NttScale& sc, u32 i, u32 log_n) {
@@ -115,8 +131,10 @@ template <class S> struct NttRaw {
 // Differences feed the twiddle multiplication with NO carry pass (fe_sub_raw: the twiddle is canonical, so the product's
 // 64-bit columns have room for limbs up to 2.5 * 2^30 and the result is below 2p for operands up to 24p); only what is
 // stored without passing through a multiplication pays a carry pass and conditional subtractions.
+// triv = 1: the tables are the plain powers of w and this pass holds the last two stages (sb == log_n): their radix-4 round
+// multiplies by 1, 1, 1 and w^(n/4) only, so it runs with one multiplication instead of four.
 template <class S> __global__ __launch_bounds__(512, (S::NL <= 9 ? 4 : 2)) void k_ntt_pass(u32* __restrict__ data, const u32* __restrict__ tw, u32 log_n,
-                                                  u32 sa, u32 sb, int dit, int last, u32 log_i, NttScale sc) {
+                                                  u32 sa, u32 sb, int dit, int last, u32 log_i, int triv, NttScale sc) {
     typedef S C;
     typedef Fe<S> Fr;
     extern __shared__ __align__(16) u32 lds[];
@@ -130,7 +148,11 @@ template <class S> __global__ __launch_bounds__(512, (S::NL <= 9 ? 4 : 2)) void 
         const u32 q = le & (I - 1), D = le >> log_i, sp = sp0 + q;
         const u32 gi = ((sp >> Lb) << (Lb + K)) | (D << Lb) | (sp & inner_mask);
         Fr v = ld_fr<S>(data + (size_t)gi * S::EW);
-        if (sc.mode && sc.when == 1) v = fe_mul<C>(v, ntt_scale_factor<S>(sc, gi, log_n));
+        if (sc.mode == 3) {
+            const Fr ab = fe_mul<C>(fe_mul<C>(v, ld_fr<S>(sc.lo + (size_t)gi * S::EW)), ld_fr<S>(sc.aux));
+            v = fe_sub<C>(ab, fe_mul<C>(ld_fr<S>(sc.hi + (size_t)gi * S::EW), ld_fr<S>(sc.aux + S::EW)));
+        } else if (sc.mode && sc.when == 1) v = fe_mul<C>(v, ntt_scale_factor<S>(sc, gi, log_n));
+        else if (triv && (dit || sa == 0)) v = fe_csub<C, 4>(v);      // any EW-word input is below 8p: the multiplication-free round wants < 4p
         lds_st<S>(lds, le, E, v);
     }
     __syncthreads();
@@ -141,8 +163,33 @@ template <class S> __global__ __launch_bounds__(512, (S::NL <= 9 ? 4 : 2)) void 
         const u32 dlo = dit ? t : (K - 2 - t);
         const u32 s_first = dit ? (sb - 1 - t) : (sa + t);           // first executed stage
         const u32 s_second = dit ? (s_first - 1) : (s_first + 1);
-        const u32* tab1 = tw + ((size_t)n - (n >> s_first)) * S::EW;
-        const u32* tab2 = tw + ((size_t)n - (n >> s_second)) * S::EW;
+        const u32 tab1 = n - (n >> s_first), tab2 = n - (n >> s_second);     // first entries of the two stages' tables
+        if (triv && dlo == 0 && Lb == 0 && (dit ? t == 0 : t + 2 == K)) {
+            // the last two stages of the transform (executed first by DIT): twiddles 1, 1, 1 and w4 = w^(n/4)
+            const Fr w4 = lds_ld<S>(tw, (dit ? tab2 : tab1) + 1, n);      // second entry of stage log_n - 2
+            for (u32 u = threadIdx.x; u < (E >> 2); u += blockDim.x) {
+                const u32 q = u & (I - 1), Db = (u >> log_i) << 2;
+                const u32 p00 = (Db << log_i) | q, p01 = ((Db | 1u) << log_i) | q, p10 = ((Db | 2u) << log_i) | q, p11 = ((Db | 3u) << log_i) | q;
+                const Fr x00 = lds_ld<S>(lds, p00, E), x01 = lds_ld<S>(lds, p01, E), x10 = lds_ld<S>(lds, p10, E), x11 = lds_ld<S>(lds, p11, E);
+                if (!dit) {          // inputs < 4p; outputs < 16p, taken by the store's full reduction (or its scale multiplication)
+                    const Fr S0 = fe_add_lazy<C>(x00, x10), S1 = fe_add_lazy<C>(x01, x11);
+                    const Fr D0 = fe_sub_lazy<C, 4>(x00, x10), B1 = fe_mul<C>(fe_sub_raw<C, 8, LB>(x01, x11), w4);
+                    lds_st<S>(lds, p00, E, fe_add_lazy<C>(S0, S1));
+                    lds_st<S>(lds, p01, E, fe_sub_lazy<C, 8>(S0, S1));
+                    lds_st<S>(lds, p10, E, fe_add_lazy<C>(D0, B1));
+                    lds_st<S>(lds, p11, E, fe_sub_lazy<C, 2>(D0, B1));
+                } else {             // inputs < 4p; outputs < 16p, and each later round adds at most 4p
+                    const Fr a00 = fe_add_lazy<C>(x00, x01), a01 = fe_sub_lazy<C, 4>(x00, x01);
+                    const Fr a10 = fe_add_lazy<C>(x10, x11), u1 = fe_mul<C>(fe_sub_raw<C, 8, LB>(x10, x11), w4);
+                    lds_st<S>(lds, p00, E, fe_add_lazy<C>(a00, a10));
+                    lds_st<S>(lds, p01, E, fe_add_lazy<C>(a01, u1));
+                    lds_st<S>(lds, p10, E, fe_sub_lazy<C, 8>(a00, a10));
+                    lds_st<S>(lds, p11, E, fe_sub_lazy<C, 2>(a01, u1));
+                }
+            }
+            __syncthreads();
+            continue;
+        }
         for (u32 u = threadIdx.x; u < (E >> 2); u += blockDim.x) {
             const u32 q = u & (I - 1), dq = u >> log_i;
             const u32 low = dq & ((1u << dlo) - 1);
@@ -155,9 +202,9 @@ template <class S> __global__ __launch_bounds__(512, (S::NL <= 9 ? 4 : 2)) void 
             if (!dit) {
                 // stage s pairs over the HIGH bit (distance 2 << dlo), twiddle depends on the low bit;
                 // stage s+1 pairs over the LOW bit, one twiddle for the whole unit
-                const Fr wa0 = ld_fr<S>(tab1 + (size_t)((low << Lb) | inner) * S::EW);
-                const Fr wa1 = ld_fr<S>(tab1 + (size_t)((((1u << dlo) | low) << Lb) | inner) * S::EW);
-                const Fr wb = ld_fr<S>(tab2 + (size_t)((low << Lb) | inner) * S::EW);
+                const Fr wa0 = lds_ld<S>(tw, tab1 + ((low << Lb) | inner), n);
+                const Fr wa1 = lds_ld<S>(tw, tab1 + ((((1u << dlo) | low) << Lb) | inner), n);
+                const Fr wb = lds_ld<S>(tw, tab2 + ((low << Lb) | inner), n);
                 // differences first: the four inputs are dead after these four lines (register pressure, not arithmetic, orders this)
                 const Fr D0 = fe_sub_raw<C, 8, LB>(x00, x10), D1 = fe_sub_raw<C, 8, LB>(x01, x11);
                 Fr S0 = fe_add_nocarry<C>(x00, x10), S1 = fe_add_nocarry<C>(x01, x11);                 // < 8p, limbs < 2^30
@@ -169,9 +216,9 @@ template <class S> __global__ __launch_bounds__(512, (S::NL <= 9 ? 4 : 2)) void 
                 lds_st<S>(lds, p11, E, fe_mul<C>(fe_sub_raw<C, 2, LB>(B0, B1), wb));
             } else {
                 // stage s1 pairs over the LOW bit, one twiddle; stage s1-1 pairs over the HIGH bit, twiddle depends on the low bit
-                const Fr w1 = ld_fr<S>(tab1 + (size_t)((low << Lb) | inner) * S::EW);
-                const Fr w20 = ld_fr<S>(tab2 + (size_t)((low << Lb) | inner) * S::EW);
-                const Fr w21 = ld_fr<S>(tab2 + (size_t)((((1u << dlo) | low) << Lb) | inner) * S::EW);
+                const Fr w1 = lds_ld<S>(tw, tab1 + ((low << Lb) | inner), n);
+                const Fr w20 = lds_ld<S>(tw, tab2 + ((low << Lb) | inner), n);
+                const Fr w21 = lds_ld<S>(tw, tab2 + ((((1u << dlo) | low) << Lb) | inner), n);
                 const Fr t0 = fe_mul<C>(x01, w1), t1 = fe_mul<C>(x11, w1);                      // products: < 2p, normalised
                 const Fr a00 = fe_add_nocarry<C>(x00, t0), a01 = fe_sub_raw<C, 2, LB>(x00, t0);  // < 6p, limbs < 2^30 / 1.5 * 2^30
                 const Fr a10 = fe_add_nocarry<C>(x10, t1), a11 = fe_sub_raw<C, 2, LB>(x10, t1);
@@ -190,13 +237,13 @@ template <class S> __global__ __launch_bounds__(512, (S::NL <= 9 ? 4 : 2)) void 
         const u32 s = dit ? (sb - 1 - t) : (sa + t);
         const u32 tl = s - sa;
         const u32 dshift = K - 1 - tl, dist = 1u << dshift;
-        const u32* table = tw + ((size_t)n - (n >> s)) * S::EW;
+        const u32 table = n - (n >> s);
         for (u32 u = threadIdx.x; u < (E >> 1); u += blockDim.x) {
             const u32 q = u & (I - 1), dp = u >> log_i;
             const u32 low = dp & (dist - 1);
             const u32 D0 = ((dp >> dshift) << (dshift + 1)) | low, D1 = D0 | dist;
             const u32 j = (low << Lb) | ((sp0 + q) & inner_mask);
-            const Fr w = ld_fr<S>(table + (size_t)j * S::EW);
+            const Fr w = lds_ld<S>(tw, table + j, n);
             const u32 pa = (D0 << log_i) | q, pb = (D1 << log_i) | q;
             const Fr a = lds_ld<S>(lds, pa, E), b = lds_ld<S>(lds, pb, E);
             if (!dit) {
@@ -224,18 +271,6 @@ template <class S> __global__ __launch_bounds__(512, (S::NL <= 9 ? 4 : 2)) void 
             st_fr_weak<S>(v, data + (size_t)gi * S::EW);
         }
     }
-}
-
-// computeH pointwise step: a[i] = (a[i] * b[i] - c[i]) * den   (all words external Montgomery)
-// k1 = internal form of den * 2^5, k2 = internal form of den (see bn254_field.h on the 2^-5 reading)
-template <class S> __global__ void k_h_pointwise(u32* __restrict__ a, const u32* __restrict__ b, const u32* __restrict__ c,
-                              const u32* __restrict__ k1k2, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const Fe<S> k1 = ld_fr<S>(k1k2), k2 = ld_fr<S>(k1k2 + S::EW);
-    Fe<S> ab = fe_mul<S>(fe_mul<S>(ld_fr<S>(a + i * S::EW), ld_fr<S>(b + i * S::EW)), k1);
-    Fe<S> cd = fe_mul<S>(ld_fr<S>(c + i * S::EW), k2);
-    st_fr<S>(fe_sub<S>(ab, cd), a + i * S::EW);
 }
 
 }  // namespace dvn

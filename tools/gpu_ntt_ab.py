@@ -21,6 +21,13 @@ for ln in (int(a) for a in (sys.argv[1:] or ["24", "20"])):
             ctx.ntt(dom, dx, binv, bdec, bcoset); b.append(ctx.last_kernel_ms(0))
         res[name] = round(float(np.median(a)), 4); res[name + "_back"] = round(float(np.median(b)), 4)
     x1 = np.empty_like(x0); ctx.d2h(x1, dx)
+    if ln <= 24:
+        da, db, dc, dh = (ctx.synthetic_scalars(10 + s, 0, 1 << ln) for s in (1, 2, 3, 4))
+        hs = []
+        for _ in range(5):
+            ctx.compute_h_device(dom, da, db, dc, 1 << ln, dh); hs.append(ctx.last_kernel_ms(0))
+        res["compute_h"] = round(float(np.median(hs)), 4)
+        for d in (da, db, dc, dh): ctx.free(d)
     print(f"log_n={ln} round_trip={bool((x0 == x1).all())} ms={res}", flush=True)
     ctx.free(dx); dom.free()
 ctx.close()
