@@ -169,6 +169,7 @@ def load_library():
         "dvn_msm_g1_share_submit": (i32, [vp, vp, sz, sz, vp, u32, u32, u32, C.POINTER(i32)]),
         "dvn_msm_g1_share_collect": (i32, [vp, i32, vp]),
         "dvn_msm_g1_sum": (i32, [vp, u32, vp]),
+        "dvn_msm_g1_multi": (i32, [vp, vp, u32, sz, sz, vp, vp]),
         "dvn_groth16_prove_multi": (i32, [vp, vp, u32, vp, vp, vp, vp]),
         "dvn_groth16_prove_solved_multi": (i32, [vp, vp, u32, vp, vp, vp, vp, sz, vp, vp, vp]),
         "dvn_bw6761_groth16_prove_solved_multi": (i32, [vp, vp, u32, vp, vp, vp, vp, sz, vp, vp, vp]),
@@ -230,7 +231,7 @@ EXPORTED_SYMBOLS = [
     "dvn_prover_use_gpu", "dvn_prover_set_use_gpu", "dvn_prover_reload_env", "dvn_prover_set_prover", "dvn_prover_set_cpu_backend",
     "dvn_prover_last_backend", "dvn_prover_prove", "dvn_prover_gpu_prover", "dvn_prover_cpu_prover", "dvn_prover_setup",
     "dvn_ctx_device_count", "dvn_ctx_device", "dvn_ctx_device_ordinal", "dvn_error_string",
-    "dvn_msm_g1_share_submit", "dvn_msm_g1_share_collect", "dvn_msm_g1_sum",
+    "dvn_msm_g1_share_submit", "dvn_msm_g1_share_collect", "dvn_msm_g1_sum", "dvn_msm_g1_multi",
     "dvn_groth16_prove_multi", "dvn_groth16_prove_solved_multi", "dvn_bw6761_groth16_prove_solved_multi", "dvn_groth16_last_stats_json",
     "dvn_bls12377_pedersen_commit", "dvn_bls12381_pedersen_commit", "dvn_bw6761_pedersen_commit",
     "dvn_gnark_pk_scan", "dvn_groth16_pk_load_bytes", "dvn_groth16_pk_load_file", "dvn_groth16_pk_commitment_bases", "dvn_groth16_pk_evict",
@@ -705,6 +706,16 @@ def prove_multi(ctx: "Context", keys, witness: np.ndarray, r_mont, s_mont, solve
         fn = ctx.L.dvn_groth16_prove_solved_multi if curve == "bn254" else getattr(ctx.L, f"dvn_{curve}_groth16_prove_solved_multi")
         ctx._chk(fn(ctx.h, arr, len(keys), _host(witness), _host(a), _host(b), _host(c), a.shape[0], _host(r_mont), _host(s_mont), _host(out)))
     return {"Ar": out[0:a1].copy(), "Bs": out[a1:a1 + a2].copy(), "Krs": out[a1 + a2:2 * a1 + a2].copy()}
+
+
+def msm_g1_multi(ctx: "Context", sets, scalars: np.ndarray, off: int = 0) -> np.ndarray:
+    """One BN254 G1 MSM over all devices of a multi-device context: sets[i] is the same point set on ctx.device(i); host
+    scalars.  Returns the G1Jac image (12 words), equal to msm_g1 on one device."""
+    arr = (C.c_void_p * len(sets))(*[p.handle for p in sets])
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros(12, dtype=np.uint64)
+    ctx._chk(ctx.L.dvn_msm_g1_multi(ctx.h, arr, len(sets), off, scalars.shape[0], _host(scalars), _host(out)))
+    return out
 
 
 def prove_committed_multi(ctx: "Context", keys, witness: np.ndarray, r_mont, s_mont) -> dict:

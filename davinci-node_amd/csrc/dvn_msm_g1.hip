@@ -1,4 +1,5 @@
 // G1 instantiation of the MSM pipeline + curve-independent point-set entry points.
+#include <thread>
 #include "msm_driver.h"
 
 int32_t dvn_internal_points_download_g2(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, uint64_t* xy);   // dvn_msm_g2.hip
@@ -236,6 +237,61 @@ extern "C" int32_t dvn_msm_g1_sum(const uint64_t* jacs, uint32_t count, uint64_t
         G1::store_affine_internal(G1::affine_from_ext(w), img);                 // Z = 1 images (what the library emits)
         acc = HG::add(acc, HG::load_device_affine(img));
     }
+    HG::write_jac(acc, out_jac);
+    return DVN_OK;
+} DVN_CATCH
+
+// One MSM over ALL devices of a multi-device context: sets[i] is the same point set resident on device i.  A host thread per
+// device runs that device's share (msm_share_submit with rank i of ndev: an equal range of the rows x n entries of the
+// expanded set) on host scalars it uploads itself; the ndev partial sums are added on the host.  One process holds every
+// partial result, so no collective runs (the one-rank-per-GPU form is dvn_msm_g1_share_submit + an all-gather of 96 bytes).
+extern "C" int32_t dvn_msm_g1_multi(dvn_ctx* ctx, const dvn_points* const* sets, uint32_t nsets, size_t off, size_t n,
+                                    const uint64_t* scalars_mont, uint64_t out_jac[12]) try {
+    typedef dvn_host::HG1 HG;
+    if (!ctx) return fail(DVN_ERR_INVALID_ARG, "ctx is NULL");
+    if (!sets || !out_jac || (!scalars_mont && n)) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    const uint32_t ndev = 1 + (uint32_t)ctx->peers.size();
+    if (nsets != ndev) return fail(DVN_ERR_INVALID_ARG, "%u point sets for a context of %u devices: one set per device", nsets, ndev);
+    for (uint32_t i = 0; i < ndev; ++i) {
+        const dvn_points* p = sets[i];
+        dvn_ctx* ci = i == 0 ? ctx : ctx->peers[i - 1];
+        if (!p) return fail(DVN_ERR_INVALID_ARG, "sets[%u] is NULL", i);
+        if (p->curve != 1 || p->suite != 0) return fail(DVN_ERR_INVALID_ARG, "sets[%u] is not BN254 G1", i);
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p->d) != hipSuccess) { (void)hipGetLastError(); return fail(DVN_ERR_INVALID_ARG, "sets[%u] does not point at device memory", i); }
+        if (at.device != ci->device) return fail(DVN_ERR_INVALID_ARG, "sets[%u] lives on device %d, the context's device %u is %d", i, at.device, i, ci->device);
+        if (p->n != sets[0]->n || p->expand_c != sets[0]->expand_c || p->nexp != sets[0]->nexp)
+            return fail(DVN_ERR_INVALID_ARG, "sets[%u] is not the same point set as sets[0] (length or table layout differs)", i);
+        if (off > p->n || n > p->n - off) return fail(DVN_ERR_INVALID_ARG, "len(points) != len(scalars): range [%zu, %zu) outside point set of %zu", off, off + n, p->n);
+    }
+    std::vector<HG::X> parts(ndev, HG::infinity());
+    std::vector<int32_t> rcs(ndev, DVN_OK);
+    std::vector<std::string> errs(ndev);
+    std::vector<std::thread> threads;
+    threads.reserve(ndev);                                      // no reallocation (and no throw) once a thread runs
+    bool spawn_failed = false;
+    for (uint32_t i = 0; i < ndev && !spawn_failed; ++i) {
+        try {
+        threads.emplace_back([&, i]() {
+            dvn_ctx* ci = i == 0 ? ctx : ctx->peers[i - 1];
+            int32_t rc = enter(ci);                             // hipSetDevice on this thread
+            if (rc == DVN_OK) {
+                std::lock_guard<std::mutex> lk(ci->mu);
+                MsmLane* L = nullptr;
+                rc = msm_share_submit<G1>(ci, sets[i], off, n, (const u32*)scalars_mont, i, ndev, &L, DVN_MSM_DEFAULT);
+                if (rc == DVN_OK) rc = msm_collect<G1>(ci, *L, &parts[i]);
+            }
+            rcs[i] = rc;
+            if (rc != DVN_OK) errs[i] = tl_error;
+        });
+        } catch (...) { spawn_failed = true; }                  // no exception may cross the C boundary
+    }
+    for (auto& t : threads) t.join();
+    if (spawn_failed) return fail(DVN_ERR_OOM, "could not start a host thread per device");
+    for (uint32_t i = 0; i < ndev; ++i)
+        if (rcs[i] != DVN_OK) return fail(rcs[i], "device share %u of %u failed: %s", i, ndev, errs[i].c_str());
+    HG::X acc = HG::infinity();
+    for (uint32_t i = 0; i < ndev; ++i) acc = HG::add(acc, parts[i]);
     HG::write_jac(acc, out_jac);
     return DVN_OK;
 } DVN_CATCH

@@ -414,7 +414,7 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
     if (total >= ((size_t)1 << 31) || (size_t)pts->nexp * pts->n >= ((size_t)1 << 31)) return fail(DVN_ERR_INVALID_ARG, "MSM too large for 31-bit entry references");
     const u32 seg = pick_segment<Cv>(total);
     const u32 nseg = (u32)((total + seg - 1) / seg);
-    // bucket reduction by marginal sums (msm_kernels.h k_bucket_marginals): nb = RH rows x RL columns
+    // bucket reduction by marginal sums (msm_kernels.h k_marginal_level): nb = RH rows x RL columns
     const u32 kl = c / 2, kh = c - 1 - kl, RL = 1u << kl, RH = 1u << kh;
     const u32 npieces = bitsum_pieces(kh, kl);
     if ((size_t)npieces * Cv::XW > DVN_HSUMS_WORDS) return fail(DVN_ERR_INVALID_ARG, "too many reduction pieces for the result buffer");
@@ -438,6 +438,7 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
     cs.take((size_t)nb * AW_ * 4);
     cs.take((size_t)nseg * AW_ * 4); cs.take((size_t)nseg * AW_ * 4);
     cs.take((size_t)(RH + RL) * Cv::XW * 4); cs.take((size_t)npieces * Cv::XW * 4);
+    cs.take((size_t)(nb / 2) * Cv::XW * 4); cs.take((size_t)(nb / 4 + 2) * Cv::XW * 4);    // marginal levels, ping and pong
     TRY(lane_ensure_ws(L, cs.off + 8192));
     Carver cv(lane_ws_base(L));
     const u32* d_scalars;
@@ -469,6 +470,7 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
     u32* edge_last = cv.take<u32>((size_t)nseg * AW_);
     u32* marg = cv.take<u32>((size_t)(RH + RL) * Cv::XW);
     u32* pieces = cv.take<u32>((size_t)npieces * Cv::XW);
+    u32* level_buf[2] = {cv.take<u32>((size_t)(nb / 2) * Cv::XW), cv.take<u32>((size_t)(nb / 4 + 2) * Cv::XW)};
 
     hipStream_t st = L.stream;
     static const bool dbg = getenv("DVN_DEBUG_SYNC") != nullptr;
@@ -510,8 +512,29 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
         k_giant_final<KC><<<64, GIANT_PIECES * LPP, (size_t)GIANT_PIECES * Cv::XW * 4, st>>>(giant_list, giant_count, giant_cap, giant_part, buckets);
         DBG_SYNC("k_giant");
     }
-    k_bucket_marginals<KC><<<RH + RL, MARG_THREADS * LPP, (size_t)MARG_THREADS * Cv::XW * 4, st>>>(buckets, marg, nb, kl);
-    DBG_SYNC("k_bucket_marginals");
+    {   // row sums R_hi (over lo) and column sums C_lo (over hi), level by level in groups of MARG_RADIX; a dimension's last
+        // level writes its part of marg (rows first, then columns)
+        u32 len_r = RL, len_c = RH;                       // entries still to be summed per row / per column
+        const u32* src_r = buckets; const u32* src_c = buckets;
+        for (u32 lvl = 0; len_r > 1 || len_c > 1; ++lvl) {
+            // groups of MARG_RADIX while there is enough work to fill the chip (throughput-bound levels), pairs afterwards: the
+            // small levels are bound by the latency of their dependent additions
+            const u32 radix = lvl == 0 || (size_t)RH * len_r >= ((size_t)1 << 17) ? MARG_RADIX : 2;     // (the buffers are sized for a first level of four)
+            const u32 rr = len_r > 1 ? (len_r < radix ? len_r : radix) : 0, rc = len_c > 1 ? (len_c < radix ? len_c : radix) : 0;
+            const u32 out_len_r = rr ? len_r / rr : 0, out_len_c = rc ? len_c / rc : 0;
+            const u32 n_rows = RH * out_len_r, n_cols = out_len_c * RL;
+            u32* buf = level_buf[lvl & 1];
+            if ((size_t)n_rows + n_cols > (lvl & 1 ? nb / 4 + 2 : nb / 2)) return fail(DVN_ERR_DEVICE, "internal: marginal level %u does not fit its buffer", lvl);
+            u32* dst_r = out_len_r == 1 ? marg : buf;
+            u32* dst_c = out_len_c == 1 ? marg + (size_t)RH * Cv::XW : buf + (size_t)n_rows * Cv::XW;
+            const size_t threads = ((size_t)n_rows + n_cols) * LPP;
+            k_marginal_level<KC><<<(unsigned)((threads + MARG_THREADS * LPP - 1) / (MARG_THREADS * LPP)), MARG_THREADS * LPP, 0, st>>>(
+                src_r, src_c, lvl == 0, dst_r, dst_c, n_rows, rr, n_cols, rc, kl);
+            if (rr) { len_r = out_len_r; src_r = dst_r; }
+            if (rc) { len_c = out_len_c; src_c = dst_c; }
+        }
+    }
+    DBG_SYNC("k_marginal_level");
     k_marginal_bitsums<KC><<<npieces, BITSUM_THREADS * LPP, sh_bytes, st>>>(marg, pieces, nb, kl);
     DBG_SYNC("k_marginal_bitsums");
     HIP_TRY(hipGetLastError());
@@ -666,11 +689,12 @@ static int32_t msm_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_
 // masked to zero digits.  A set too small to be expanded (< 2^15 points: microseconds of work) is computed whole by rank 0,
 // the other ranks contribute the point at infinity.
 template <class Cv>
-static int32_t msm_share_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, u32 rank, u32 world, MsmLane** lane_out) {
+static int32_t msm_share_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, u32 rank, u32 world, MsmLane** lane_out,
+                                uint32_t flags = DVN_MSM_SCALARS_ON_DEVICE) {
     if (off > pts->n || n > pts->n - off) return fail(DVN_ERR_INVALID_ARG, "len(points) != len(scalars): range [%zu, %zu) outside point set of %zu", off, off + n, pts->n);
     if (world == 0 || rank >= world) return fail(DVN_ERR_INVALID_ARG, "rank %u outside world %u", rank, world);
     if (n && !use_expanded(pts, n)) {
-        if (rank == 0) return msm_submit<Cv>(ctx, pts, off, n, (const uint64_t*)d_scalars, DVN_MSM_SCALARS_ON_DEVICE, lane_out);
+        if (rank == 0) return msm_submit<Cv>(ctx, pts, off, n, (const uint64_t*)d_scalars, flags, lane_out);
         n = 0;
     }
     MsmLane* L = nullptr;
@@ -682,7 +706,7 @@ static int32_t msm_share_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off,
     int32_t rc = DVN_OK;
     if (L->nwin) {
         const u32 row_lo = (u32)(flat_lo / n), row_hi = (u32)((flat_hi + n - 1) / n);
-        rc = msm_expanded<Cv>(ctx, *L, pts, off, n, (const uint64_t*)d_scalars, DVN_MSM_SCALARS_ON_DEVICE, row_lo, row_hi, flat_lo, flat_hi);
+        rc = msm_expanded<Cv>(ctx, *L, pts, off, n, (const uint64_t*)d_scalars, flags, row_lo, row_hi, flat_lo, flat_hi);
     }
     if (rc != DVN_OK) { (void)hipStreamSynchronize(L->stream); L->busy = false; return rc; }
     *lane_out = L;

@@ -855,27 +855,32 @@ __global__ __launch_bounds__(64 * Lanes<Cv>::LPP) void k_window_finalize(const u
 //     RL * sum_hi hi * R_hi  +  sum_lo (lo + 1) * C_lo,      R_hi = sum_lo B[hi][lo],   C_lo = sum_hi B[hi][lo],
 // and a weighted sum over <= 1024 marginals splits by the bits of the weight into plain subset sums,
 //     sum_e w_e M_e = sum_j 2^j * (sum over the e whose weight has bit j set of M_e).
-// Every step is a plain sum (a short serial run per thread + one LDS tree), so the dependent chain is ~25 group operations
-// where chunked running sums with their small scalar multiplications need ~60; the 2^j weights are applied on the host
-// (msm_driver.h bitsum_combine), which gets kh + kl + 1 subset sums in a few pieces each.
-// k_bucket_marginals: block b < RH sums row b, block RH + lo sums column lo; marg[b] receives the result.
-constexpr u32 MARG_THREADS = 128;
+// Every step is a plain sum, so the dependent chain is ~25 group operations where chunked running sums with their small scalar
+// multiplications need ~60; the 2^j weights are applied on the host (msm_driver.h bitsum_combine), which gets kh + kl + 1
+// subset sums in a few pieces each.
+// k_marginal_level: ONE level of both marginal sums as a grid-wide step.  Thread g < n_rows adds r_rows neighbours of a row
+// (flat groups of consecutive entries), the next n_cols threads add r_cols entries one row pitch (RL) apart.  Every lane of
+// every wave adds; the levels are separate launches (groups of four: ceil(log4) launches, three dependent additions each)
+// where an in-block tree leaves half of the lanes idle at every step and pays two barriers per step.
+// Level 1 reads the raw accumulator images of the bucket array (src_acc = 1), later levels XYZZ images.
+constexpr u32 MARG_THREADS = 128, MARG_RADIX = 4;
 template <class Cv>
-__global__ __launch_bounds__(MARG_THREADS * Lanes<Cv>::LPP) void k_bucket_marginals(const u32* __restrict__ bucket_sums, u32* __restrict__ marg, u32 nb, u32 kl) {
+__global__ __launch_bounds__(MARG_THREADS * Lanes<Cv>::LPP) void k_marginal_level(const u32* __restrict__ src_rows, const u32* __restrict__ src_cols, int src_acc,
+                                                                                u32* __restrict__ dst_rows, u32* __restrict__ dst_cols,
+                                                                                u32 n_rows, u32 r_rows, u32 n_cols, u32 r_cols, u32 kl) {
     typedef typename Cv::X X;
-    extern __shared__ __align__(16) u32 sh[];
-    const u32 RL = 1u << kl, RH = nb >> kl;
-    const u32 t = ltid<Cv>(), T = lbdim<Cv>();
-    X acc = Cv::infinity();
-    if (blockIdx.x < RH) {
-        const u32* row = bucket_sums + (size_t)blockIdx.x * RL * AccImg<Cv>::W;
-        for (u32 i = t; i < RL; i += T) acc = Cv::add(acc, ld_acc<Cv>(row + (size_t)i * AccImg<Cv>::W));
-    } else {
-        const u32* col = bucket_sums + (size_t)(blockIdx.x - RH) * AccImg<Cv>::W;
-        for (u32 i = t; i < RH; i += T) acc = Cv::add(acc, ld_acc<Cv>(col + (size_t)i * RL * AccImg<Cv>::W));
+    const size_t g = lgtid<Cv>();
+    if (g >= (size_t)n_rows + n_cols) return;
+    const u32* src; u32* dst; size_t first, stride; u32 cnt;
+    if (g < n_rows) { src = src_rows; dst = dst_rows + g * Cv::XW; first = g * r_rows; stride = 1; cnt = r_rows; }
+    else {
+        const size_t i = g - n_rows, h = i >> kl, lo = i & ((1u << kl) - 1);
+        src = src_cols; dst = dst_cols + i * Cv::XW; first = ((h * r_cols) << kl) + lo; stride = (size_t)1 << kl; cnt = r_cols;
     }
-    acc = block_sum<Cv>(acc, sh);
-    if (t == 0) st_xyzz<Cv>(acc, marg + (size_t)blockIdx.x * Cv::XW);
+    auto load = [&](size_t e) { return src_acc ? ld_acc<Cv>(src + e * AccImg<Cv>::W) : ld_xyzz<Cv>(src + e * Cv::XW); };
+    X acc = load(first);
+    for (u32 k = 1; k < cnt; ++k) acc = Cv::add(acc, load(first + k * stride));
+    st_xyzz<Cv>(acc, dst);
 }
 // k_marginal_bitsums: the subset sums of the marginals, BITSUM_SPAN marginals per block.  Blocks [0, kh * sr) take bit
 // j = block / sr of the row index hi (weight of R_hi), the next (kl + 1) * sc blocks bit j of lo + 1 (weight of C_lo);

@@ -155,6 +155,12 @@ int32_t dvn_msm_g1_share_collect(dvn_ctx* ctx, int32_t ticket, uint64_t partial_
 /* jacs: the NORMALISED images the library emits -- Z is 0 (infinity) or the Montgomery 1; any other Z is DVN_ERR_INVALID_ARG
  * (a general G1Jac, e.g. gnark's, must be brought to affine first) */
 int32_t dvn_msm_g1_sum(const uint64_t* jacs /* count x 12 */, uint32_t count, uint64_t out_jac[12]);
+/* One MSM over ALL devices of a multi-device context (dvn_init with ndev > 1), the in-process form of the shared MSM: sets[i]
+ * is the same point set uploaded on dvn_ctx_device(ctx, i); a host thread per device runs that device's share (rank i of
+ * ndev, as dvn_msm_g1_share_submit) on HOST scalars it uploads itself, and the ndev partial sums are added on the host.  One
+ * process holds every partial result, so no collective runs.  Same result as dvn_msm_g1(ctx, sets[0], ...). */
+int32_t dvn_msm_g1_multi(dvn_ctx* ctx, const dvn_points* const* sets, uint32_t nsets, size_t off, size_t n,
+                         const uint64_t* scalars_mont, uint64_t out_jac[12]);
 
 /* ---- fr/fft (replaces gnark-crypto fft.Domain) ------------------------------------- */
 #define DVN_DIF 0

@@ -90,6 +90,36 @@ def test_shared_msm_by_entry_count(ctx, pkg, orc, world):
 
 
 @pytest.mark.gpu
+def test_one_msm_over_the_devices_of_a_context(pkg):
+    """dvn_msm_g1_multi on a three-"device" context == the single-device MSM (itself checked against the oracle in
+    test_gpu_parity.py); an expanded set (every device runs a real entry range) and a plain one (device 0 computes it whole)."""
+    mc = pkg.Context([0, 0, 0])
+    devs = [mc.device(i) for i in range(3)]
+    for n, kind in ((70001, 0), (40000, 1), (900, 0)):
+        sets = [d.synthetic_g1(0xDA71C1, n) for d in devs]
+        ds = devs[0].synthetic_scalars(77, kind, n)
+        sc = np.empty((n, 4), dtype=np.uint64); devs[0].d2h(sc, ds)
+        want = devs[0].msm_g1(sets[0], sc)
+        got = pkg.msm_g1_multi(mc, sets, sc)
+        assert (got == want).all(), (n, kind)
+        if n == 70001:
+            got_off = pkg.msm_g1_multi(mc, sets, sc[:50000], off=123)
+            assert (got_off == devs[0].msm_g1(sets[0], sc[:50000], off=123)).all()
+            with pytest.raises(pkg.DvnError) as e:
+                pkg.msm_g1_multi(mc, sets[:2], sc)                   # one set per device
+            assert e.value.code == -1
+            short = devs[2].synthetic_g1(0xDA71C1, n - 1)
+            with pytest.raises(pkg.DvnError) as e:
+                pkg.msm_g1_multi(mc, [sets[0], sets[1], short], sc[:10])
+            assert "not the same point set" in str(e.value)
+            short.free()
+        devs[0].free(ds)
+        for p in sets:
+            p.free()
+    mc.close()
+
+
+@pytest.mark.gpu
 def test_one_proof_over_the_devices_of_a_context(pkg, opy, orc):
     """dvn_groth16_prove_multi / _prove_solved_multi on a three-"device" context == the single-device proof == the closed form.
     n = 2^16 - 3: every key set is an expanded table, so every device runs a real entry range."""
