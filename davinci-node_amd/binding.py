@@ -22,7 +22,8 @@ class DvnError(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(_CSRC, "libdvn_prover.so")
+    """The in-tree build; DVN_PROVER_LIB names another build of the SAME library (kernel A/B experiments)."""
+    return os.environ.get("DVN_PROVER_LIB") or os.path.join(_CSRC, "libdvn_prover.so")
 
 
 def build_library(jobs: int = 4) -> str:

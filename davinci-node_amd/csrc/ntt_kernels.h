@@ -202,8 +202,6 @@ template <class S> __global__ __launch_bounds__(512, (S::NL <= 9 ? 4 : 2)) void 
             if (!dit) {
                 // stage s pairs over the HIGH bit (distance 2 << dlo), twiddle depends on the low bit;
                 // stage s+1 pairs over the LOW bit, one twiddle for the whole unit
-                const Fr wa0 = lds_ld<S>(tw, tab1 + ((low << Lb) | inner), n);
-                const Fr wa1 = lds_ld<S>(tw, tab1 + ((((1u << dlo) | low) << Lb) | inner), n);
                 const Fr wb = lds_ld<S>(tw, tab2 + ((low << Lb) | inner), n);
                 // differences first: the four inputs are dead after these four lines (register pressure, not arithmetic, orders this)
                 const Fr D0 = fe_sub_raw<C, 8, LB>(x00, x10), D1 = fe_sub_raw<C, 8, LB>(x01, x11);
@@ -211,6 +209,10 @@ template <class S> __global__ __launch_bounds__(512, (S::NL <= 9 ? 4 : 2)) void 
                 if constexpr (NttRaw<S>::TIGHT) { S0 = fe_normalise<C>(S0); S1 = fe_normalise<C>(S1); }
                 lds_st<S>(lds, p00, E, fe_csub<C, 4>(fe_csub<C, 8>(fe_normalise<C>(fe_add_nocarry<C>(S0, S1)))));   // < 16p -> < 4p
                 lds_st<S>(lds, p01, E, fe_mul<C>(fe_sub_raw<C, 16, NttRaw<S>::SH_SUMS>(S0, S1), wb));   // operand < 24p
+                // the stage-s twiddles are fetched only now: 18 registers that would otherwise be live across the first product
+                asm volatile("" ::: "memory");
+                const Fr wa0 = lds_ld<S>(tw, tab1 + ((low << Lb) | inner), n);
+                const Fr wa1 = lds_ld<S>(tw, tab1 + ((((1u << dlo) | low) << Lb) | inner), n);
                 const Fr B0 = fe_mul<C>(D0, wa0), B1 = fe_mul<C>(D1, wa1);
                 lds_st<S>(lds, p10, E, fe_add_lazy<C>(B0, B1));                                          // two products: < 4p
                 lds_st<S>(lds, p11, E, fe_mul<C>(fe_sub_raw<C, 2, LB>(B0, B1), wb));
