@@ -165,8 +165,10 @@ template <class S> static int32_t ntt_device(dvn_ctx* ctx, const dvn_domain* d, 
     if (npass > 1) {
         const u32 end = decimation == DVN_DIF ? npass - 1 : 0;
         if (ks[end] & 1) {
-            // swap with a pass of even count, if any
-            for (u32 p = 0; p < npass; ++p) if (!(ks[p] & 1)) { const u32 t = ks[p]; ks[p] = ks[end]; ks[end] = t; break; }
+            // swap with a pass of even count; if every pass is odd, hand one stage over to a neighbour
+            bool done = false;
+            for (u32 p = 0; p < npass && !done; ++p) if (!(ks[p] & 1)) { const u32 t = ks[p]; ks[p] = ks[end]; ks[end] = t; done = true; }
+            for (u32 p = 0; p < npass && !done; ++p) if (p != end && ks[p] < kmax && ks[end] > 2) { ++ks[p]; --ks[end]; done = true; }
         }
     }
     // the butterfly network absorbs the coset scaling where its shape allows (DIT: a scaling of the input, DIF: of the output)
