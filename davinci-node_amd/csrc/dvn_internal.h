@@ -44,6 +44,7 @@ struct dvn_ctx {
     int device = 0;
     MsmLane lane[DVN_LANES];
     hipEvent_t ev_dep = nullptr;
+    bool dep_hold = false;    // lanes acquired while set wait for ev_dep as it was last recorded (not for later main-stream work)
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // 0/1: whole device section, 2/3: dominant kernel
     float last_ms[2] = {0.f, 0.f};
@@ -133,6 +134,27 @@ static inline int32_t enter(dvn_ctx* ctx) {
     if (!ctx) return fail(DVN_ERR_INVALID_ARG, "ctx is NULL");
     if (ctx->force_fail) return fail(DVN_ERR_INJECTED, "DVN_FORCE_FAIL is set: injected device failure");
     HIP_TRY(hipSetDevice(ctx->device));
+    return DVN_OK;
+}
+// Zero `bytes` (a multiple of 4) at p (4-byte aligned) on a stream, with a kernel of small workgroups: the runtime's memset
+// kernel wants a whole CU's worth of free wave slots and registers, so queued behind a long VALU-bound kernel on another stream
+// it (and everything after it on its stream) waits until that kernel drains; 256-thread groups of a dozen registers slip in.
+static __global__ void k_zero_fill(u32* __restrict__ p, size_t words) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t head = std::min<size_t>(words, ((16 - ((size_t)p & 15)) & 15) / 4);       // words before the first 16-byte boundary
+    uint4* q = reinterpret_cast<uint4*>(p + head);
+    const size_t n16 = (words - head) / 4;
+    for (size_t i = t; i < n16; i += stride) q[i] = make_uint4(0, 0, 0, 0);
+    if (t < head) p[t] = 0;
+    const size_t tail0 = head + n16 * 4;
+    if (t < words - tail0) p[tail0 + t] = 0;
+}
+static inline int32_t dvn_zero_async(void* p, size_t bytes, hipStream_t st) {
+    if (!bytes) return DVN_OK;
+    const size_t words = bytes / 4;
+    const unsigned blocks = (unsigned)std::min<size_t>((words / 4 + 255) / 256 + 1, 4096);
+    k_zero_fill<<<blocks, 256, 0, st>>>((u32*)p, words);
+    HIP_TRY(hipGetLastError());
     return DVN_OK;
 }
 static inline int32_t ensure_ws(dvn_ctx* ctx, size_t bytes) {

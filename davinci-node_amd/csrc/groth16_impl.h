@@ -14,6 +14,7 @@
 // A suite SU supplies: FrC (scalar config), G1T / G2T, H1 / H2 (host finishing arithmetic), SUITE, r_words(), g1_gen(),
 // g2_gen(), domain_create, compute_h and the MSM submit / collect calls (cross-TU for BN254, direct elsewhere).
 #pragma once
+#include <chrono>
 #include <algorithm>
 #include <future>
 #include <thread>
@@ -91,11 +92,13 @@ struct dvn_groth16_pk {
 
 // out[row] = sum_k coef[k] * w[idx[k]]; w are gnark Montgomery words (read as x*2^-5 internal), coef true internal:
 // the product is again a gnark Montgomery word.
+// Rows [rows, rows_padded) are written as zeros (the vector is zero-padded to the domain size).
 template <class S> __global__ void k_r1cs_matvec(const u32* __restrict__ ptr, const u32* __restrict__ idx, const u32* __restrict__ coef,
-                                     const u32* __restrict__ w, u32* __restrict__ out, u32 rows) {
+                                     const u32* __restrict__ w, u32* __restrict__ out, u32 rows, u32 rows_padded) {
     u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
+    if (r >= rows_padded) return;
     Fe<S> acc = fe_zero<S>();
+    if (r >= rows) { st_fr<S>(acc, out + (size_t)r * S::EW); return; }
     for (u32 k = ptr[r]; k < ptr[r + 1]; ++k)
         acc = fe_add<S>(acc, fe_mul<S>(ld_fr<S>(coef + (size_t)k * S::EW), ld_fr<S>(w + (size_t)idx[k] * S::EW)));
     st_fr<S>(acc, out + (size_t)r * S::EW);
@@ -499,6 +502,7 @@ template <class SU> static int32_t groth16_setup(dvn_ctx* ctx, const dvn_r1cs* c
 // ------------------------------------------------------------------------------------------------------
 // Prove
 // ------------------------------------------------------------------------------------------------------
+#define TRY_HOLD(expr) do { int32_t _rc = (expr); if (_rc != DVN_OK) { ctx->dep_hold = false; return _rc; } } while (0)
 template <class SU> struct MsmResults { typename SU::H1::X mA, mB, mK, mZ; typename SU::H2::X mB2; };
 
 // Device part of a proof.  world == 1: the five full MSMs.  world > 1 (sharded proving):
@@ -528,6 +532,9 @@ template <class SU> static int32_t groth16_device(dvn_ctx* ctx, dvn_groth16_pk* 
     pk->h2d_bytes = 0; pk->last_rank = rank; pk->last_world = world;
     auto body = [&]() -> int32_t {
         MsmLane *&l2 = lanes[0], *&lA = lanes[1], *&lB = lanes[2], *&lK = lanes[3], *&lZ = lanes[4];
+        static const bool trace_host = getenv("DVN_TRACE_HOST") != nullptr;
+        const auto th0 = std::chrono::steady_clock::now();
+        auto tmark = [&](const char* what) { if (trace_host) fprintf(stderr, "[dvn host] %8.3f ms %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count(), what); };
         HIP_TRY(hipEventRecord(e0, st));
         if (!(flags & 2)) {    // flags & 2: the (completed) witness already sits in pk->d_w (committed proofs)
             RoctxRange rr("dvn:witness_copy");
@@ -539,45 +546,65 @@ template <class SU> static int32_t groth16_device(dvn_ctx* ctx, dvn_groth16_pk* 
             RoctxRange rr("dvn:wire_filter");
             if (pk->nA) k_gather_fr<S::EW><<<(unsigned)((pk->nA + 255) / 256), 256, 0, st>>>(pk->d_w, pk->d_idxA, pk->d_wA, pk->nA);
             if (pk->nB) k_gather_fr<S::EW><<<(unsigned)((pk->nB + 255) / 256), 256, 0, st>>>(pk->d_w, pk->d_idxB, pk->d_wB, pk->nB);
+            // imported key: K's wires are an index list (private minus committed)
+            if (pk->d_idxK && pk->nK) k_gather_fr<S::EW><<<(unsigned)((pk->nK + 255) / 256), 256, 0, st>>>(pk->d_w, pk->d_idxK, pk->d_wK, pk->nK);
             HIP_TRY(hipGetLastError());
         }
         // (6) the four MSMs that need only the wire values go to four lanes at once (a lane waits for what the main stream
         // holds at submit time, i.e. the gathers): their sorts and latency-bound bucket reductions overlap each other ...
-        { RoctxRange rr("dvn:msm_submit:G2.B"); TRY(submit_g2(pk->B2, pk->nB, pk->d_wB, &l2)); }
-        { RoctxRange rr("dvn:msm_submit:G1.A"); TRY(submit_g1(pk->A, pk->nA, pk->d_wA, &lA)); }
-        { RoctxRange rr("dvn:msm_submit:G1.B"); TRY(submit_g1(pk->B, pk->nB, pk->d_wB, &lB)); }
+        static const int solve_first = [] { const char* e = getenv("DVN_G16_SOLVE_FIRST"); return e ? atoi(e) : 0; }();
+        auto queue_solve = [&]() -> int32_t {
+            // ... while the main stream runs (1) the "solve" a = A w, b = B w, c = C w (zero padded to the domain size) and
+            // (3) h = computeH(a, b, c), which stays on the device as the scalar vector of the Z MSM
+            if (abc_host) {                                    // the solver's (a, b, c) from host memory: their upload runs under the wire-only MSMs
+                RoctxRange rr("dvn:abc_copy");
+                for (int q = 0; q < 3; ++q) {
+                    if (abc_len) HIP_TRY(hipMemcpyAsync(pk->d_abc + (size_t)q * n * EW, abc_host[q], abc_len * EB, hipMemcpyHostToDevice, st));
+                    TRY(dvn_zero_async(pk->d_abc + ((size_t)q * n + abc_len) * EW, (n - abc_len) * EB, st));      // zero padding to the domain size
+                }
+                pk->h2d_bytes += 3 * abc_len * EB;
+            } else if (!(flags & 4)) {                         // flags & 4: (a, b, c) already sit zero-padded in pk->d_abc
+                RoctxRange rr("dvn:r1cs_matvec");
+                for (int q = 0; q < 3; ++q)
+                    k_r1cs_matvec<S><<<(unsigned)((n + 127) / 128), 128, 0, st>>>(pk->d_ptr[q], pk->d_idx[q], pk->d_coef[q], pk->d_w,
+                                                                                  pk->d_abc + (size_t)q * n * EW, (u32)pk->n_constraints, (u32)n);
+                HIP_TRY(hipGetLastError());
+            }
+            { RoctxRange rr("dvn:compute_h"); TRY(SU::compute_h(ctx, pk->dom, pk->d_abc, pk->d_abc + n * EW, pk->d_abc + 2 * n * EW)); }
+            HIP_TRY(hipEventRecord(e1, st));
+            return DVN_OK;
+        };
+        if (solve_first) {
+            // the solve and computeH go to the main stream FIRST; the lanes wait for the gathers only (ev_dep recorded here, held)
+            HIP_TRY(hipEventRecord(ctx->ev_dep, st));
+            ctx->dep_hold = true;
+            const int32_t rcs = queue_solve();
+            if (rcs != DVN_OK) { ctx->dep_hold = false; return rcs; }
+        }
+        tmark("gathers queued");
+        { RoctxRange rr("dvn:msm_submit:G2.B"); TRY_HOLD(submit_g2(pk->B2, pk->nB, pk->d_wB, &l2)); }
+        tmark("G2.B submitted");
+        { RoctxRange rr("dvn:msm_submit:G1.A"); TRY_HOLD(submit_g1(pk->A, pk->nA, pk->d_wA, &lA)); }
+        tmark("G1.A submitted");
+        { RoctxRange rr("dvn:msm_submit:G1.B"); TRY_HOLD(submit_g1(pk->B, pk->nB, pk->d_wB, &lB)); }
+        tmark("G1.B submitted");
         size_t nK = 0;
         {
             RoctxRange rr("dvn:msm_submit:G1.K");
-            if (pk->d_idxK) {                                  // imported key: K's wires are an index list (private minus committed)
-                if (pk->nK) k_gather_fr<S::EW><<<(unsigned)((pk->nK + 255) / 256), 256, 0, st>>>(pk->d_w, pk->d_idxK, pk->d_wK, pk->nK);
-                HIP_TRY(hipGetLastError());
+            if (pk->d_idxK) {
                 nK = pk->nK;
-                TRY(submit_g1(pk->K, pk->nK, pk->d_wK, &lK));
-            } else { nK = m - pk->k_first; TRY(submit_g1(pk->K, nK, pk->d_w + pk->k_first * EW, &lK)); }
+                TRY_HOLD(submit_g1(pk->K, pk->nK, pk->d_wK, &lK));
+            } else { nK = m - pk->k_first; TRY_HOLD(submit_g1(pk->K, nK, pk->d_w + pk->k_first * EW, &lK)); }
         }
-        // ... while the main stream runs (1) the "solve" a = A w, b = B w, c = C w (zero padded to the domain size) and
-        // (3) h = computeH(a, b, c), which stays on the device as the scalar vector of the Z MSM
-        if (abc_host) {                                    // the solver's (a, b, c) from host memory: their upload runs under the wire-only MSMs
-            RoctxRange rr("dvn:abc_copy");
-            HIP_TRY(hipMemsetAsync(pk->d_abc, 0, 3 * n * EB, st));
-            for (int q = 0; q < 3; ++q)
-                if (abc_len) HIP_TRY(hipMemcpyAsync(pk->d_abc + (size_t)q * n * EW, abc_host[q], abc_len * EB, hipMemcpyHostToDevice, st));
-            pk->h2d_bytes += 3 * abc_len * EB;
-        } else if (!(flags & 4)) {                         // flags & 4: (a, b, c) already sit zero-padded in pk->d_abc
-            RoctxRange rr("dvn:r1cs_matvec");
-            HIP_TRY(hipMemsetAsync(pk->d_abc, 0, 3 * n * EB, st));
-            for (int q = 0; q < 3; ++q)
-                k_r1cs_matvec<S><<<(unsigned)((pk->n_constraints + 127) / 128), 128, 0, st>>>(pk->d_ptr[q], pk->d_idx[q], pk->d_coef[q], pk->d_w,
-                                                                                          pk->d_abc + (size_t)q * n * EW, (u32)pk->n_constraints);
-            HIP_TRY(hipGetLastError());
-        }
-        { RoctxRange rr("dvn:compute_h"); TRY(SU::compute_h(ctx, pk->dom, pk->d_abc, pk->d_abc + n * EW, pk->d_abc + 2 * n * EW)); }
-        HIP_TRY(hipEventRecord(e1, st));
+        ctx->dep_hold = false;
+        if (!solve_first) TRY(queue_solve());
+        tmark("MSMs and computeH queued");
         // Z takes the first lane that frees up: its submit makes the lane wait for computeH
         RoctxRange rc_("dvn:msm_collect");
         TRY(SU::msm_collect_g1(ctx, lA, &out->mA)); pk->msm_ms[0] = lA->ms[0]; pk->msm_pairs[0] = pk->nA; lA = nullptr;
+        tmark("A collected");
         { RoctxRange rr("dvn:msm_submit:G1.Z"); TRY(submit_g1(pk->Z, n - 1, pk->d_abc, &lZ)); }                // h[:n-1] against Z[:n-1]
+        tmark("Z submitted");
         TRY(SU::msm_collect_g1(ctx, lB, &out->mB)); pk->msm_ms[1] = lB->ms[0]; pk->msm_pairs[1] = pk->nB; lB = nullptr;
         TRY(SU::msm_collect_g1(ctx, lK, &out->mK)); pk->msm_ms[2] = lK->ms[0]; pk->msm_pairs[2] = nK; lK = nullptr;
         TRY(SU::msm_collect_g1(ctx, lZ, &out->mZ)); pk->msm_ms[3] = lZ->ms[0]; pk->msm_pairs[3] = n - 1; lZ = nullptr;

@@ -202,19 +202,9 @@ template <class S> static int32_t digits_hist_attr(int device) {
 static inline size_t s1_lds(u32 lb) { return ((size_t)3 * lb + 80 + 2 * ST) * 4; }
 static inline size_t s2_lds() { return ((size_t)4 * 1024 + 80 + ST) * 4 + (size_t)ST * 2; }
 
-// zero `bytes` (a multiple of 4) on the lane's stream: hipMemsetAsync, or a fill kernel on the allocation-free path (callers
-// that may sit under HIP graph capture, where recorded memset nodes are to be avoided)
-static __global__ void k_zero_words(u32* __restrict__ p, size_t words) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) p[i] = 0;
-}
-static inline int32_t lane_zero(MsmLane& L, void* p, size_t bytes, hipStream_t st) {
-    if (!L.ext_ws) { HIP_TRY(hipMemsetAsync(p, 0, bytes, st)); return DVN_OK; }
-    const size_t words = bytes / 4;
-    const unsigned blocks = (unsigned)std::min<size_t>((words + 255) / 256, 2048);
-    k_zero_words<<<blocks ? blocks : 1, 256, 0, st>>>((u32*)p, words);
-    HIP_TRY(hipGetLastError());
-    return DVN_OK;
-}
+// zero `bytes` (a multiple of 4) on the lane's stream: always a fill kernel of small workgroups (dvn_zero_async), never the
+// runtime's memset -- that one cannot start beside another lane's accumulation, and it is not to be recorded under graph capture
+static inline int32_t lane_zero(MsmLane& L, void* p, size_t bytes, hipStream_t st) { (void)L; return dvn_zero_async(p, bytes, st); }
 
 // Plain point sets, two-pass staged sort: one globally sorted entry list over the virtual buckets (window, bucket);
 // the accumulate / fix kernels see ONE window of W * nb buckets, the reduction runs per real window afterwards.
@@ -639,7 +629,8 @@ static inline int32_t lane_acquire(dvn_ctx* ctx, MsmLane** out) {
         MsmLane& L = ctx->lane[k];
         if (!L.busy) {
             // work queued earlier on the context's main stream (gathers, computeH, uploads) must be visible to this lane
-            HIP_TRY(hipEventRecord(ctx->ev_dep, ctx->stream));
+            // (a caller that has queued main-stream work the lane does NOT depend on records ev_dep itself and sets dep_hold)
+            if (!ctx->dep_hold) HIP_TRY(hipEventRecord(ctx->ev_dep, ctx->stream));
             HIP_TRY(hipStreamWaitEvent(L.stream, ctx->ev_dep, 0));
             L.busy = true; L.seq++;
             L.ext_ws = nullptr; L.ext_bytes = 0;
