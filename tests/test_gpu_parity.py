@@ -302,7 +302,7 @@ def test_ntt_golden_vectors(ctx, vectors, conv):
         d.free()
 
 
-@pytest.mark.parametrize("log_n", [1, 2, 3, 5, 8, 9, 11, 12, 16, 17, 19, 22])
+@pytest.mark.parametrize("log_n", [1, 2, 3, 5, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22])
 def test_ntt_all_modes_vs_oracle(ctx, orc, log_n):
     n = 1 << log_n
     dom = ctx.domain(log_n)
@@ -345,6 +345,12 @@ def test_ntt_full_size_properties(ctx, orc, pkg):
     assert (y == orc.ntt(x, False, pkg.DIF, False)).all()
     ctx.ntt(dom, dx, True, pkg.DIT, True); ctx.d2h(y, dx)
     assert (y == orc.ntt(orc.ntt(x, False, pkg.DIF, False), True, pkg.DIT, True)).all()
+    # the two coset kinds whose shift lives in the twiddle tables (what computeH runs): FFT(DIT, coset) and FFTInverse(DIF, coset)
+    ctx.h2d(dx, x); ctx.ntt(dom, dx, False, pkg.DIT, True); ctx.d2h(y, dx)
+    want = orc.ntt(x, False, pkg.DIT, True)
+    assert (y == want).all()
+    ctx.ntt(dom, dx, True, pkg.DIF, True); ctx.d2h(y, dx)
+    assert (y == orc.ntt(want, True, pkg.DIF, True)).all()
     ctx.free(dx); dom.free()
 
 
