@@ -363,7 +363,7 @@ def test_compute_h_golden_vectors(ctx, vectors, conv):
         dom.free()
 
 
-@pytest.mark.parametrize("log_n,m", [(3, 5), (10, 1000), (16, (1 << 16) - 3), (18, 1 << 18), (21, (1 << 21) - 77)])
+@pytest.mark.parametrize("log_n,m", [(1, 2), (2, 3), (3, 5), (10, 1000), (14, 9000), (16, (1 << 16) - 3), (18, 1 << 18), (20, 1 << 20), (21, (1 << 21) - 77)])
 def test_compute_h_vs_oracle(ctx, orc, log_n, m):
     dom = ctx.domain(log_n)
     a, b, c = orc.scalars(3, 0, m), orc.scalars(4, 0, m), orc.scalars(5, 0, m)
