@@ -17,7 +17,7 @@ extern "C" int32_t dvn_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uin
 
 // Sharded proving (BASELINE config 5: the proof's MSMs sharded across the GPUs of a node): rank `rank` of `world` computes its
 // rows of the five MSMs (dvn_groth16_prove_shard, 72 uint64 of partial results), the ranks all-gather them, and every rank (or
-// one) assembles the proof on the host (dvn_groth16_prove_combine).  Needs expanded key sets (>= 2^15 points each).
+// one) assembles the proof on the host (dvn_groth16_prove_combine).  Key sets too small to be expanded (< 2^10 points) are computed whole by rank 0.
 extern "C" int32_t dvn_groth16_prove_shard(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
                                            uint32_t rank, uint32_t world, uint64_t partial_out[72]) try {
     return groth16_prove_shard<SuiteBn254>(ctx, pk, witness, flags, rank, world, partial_out);
@@ -230,6 +230,12 @@ static int32_t committed_prepare(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_
     constexpr u32 EW = 8;
     hipStream_t st = ctx->stream;
     HIP_TRY(hipMemcpyAsync(pk->d_w, witness, pk->m * EW * 4, (flags & 1) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    // the public wires the challenge hashes (they are the first n_public wires): from the caller's host copy, or in ONE copy back
+    // that runs under the two MSMs below
+    std::vector<u32> pubw((size_t)pk->n_public * EW);
+    for (u32 wi : pk->public_committed) if (wi >= pk->n_public) return fail(DVN_ERR_INVALID_ARG, "internal: committed public wire %u is not a public wire", wi);
+    if (flags & 1) HIP_TRY(hipMemcpyAsync(pubw.data(), pk->d_w, pubw.size() * 4, hipMemcpyDeviceToHost, st));
+    else memcpy(pubw.data(), witness, pubw.size() * 4);
     // (1) the commitment hint: two MSMs over the committed wires, in flight together
     const u32* d_committed = pk->d_w + (size_t)pk->n_public * EW;
     MsmLane *lc = nullptr, *lp = nullptr;
@@ -241,18 +247,14 @@ static int32_t committed_prepare(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_
     const int32_t rc2 = SU::msm_collect_g1(ctx, lp, &k);
     if (rc != DVN_OK) return rc;
     TRY(rc2);
+    if (flags & 1) HIP_TRY(hipStreamSynchronize(st));        // the public wires have arrived (long since: the MSMs were queued behind the copy)
     uint64_t j[12];
     H1::write_jac(c, j); memcpy(commitment_out, j, 64); if (H1::is_inf(c)) memset(commitment_out, 0, 64);
     H1::write_jac(k, j); memcpy(pok_out, j, 64); if (H1::is_inf(k)) memset(pok_out, 0, 64);
     // challenge = keccak256(C.x || C.y || publicCommitted...) mod r
     std::vector<uint8_t> buf(64 + 32 * pk->public_committed.size());
     fp_ext_to_be32((const u32*)commitment_out, buf.data()); fp_ext_to_be32((const u32*)commitment_out + 8, buf.data() + 32);
-    for (size_t i = 0; i < pk->public_committed.size(); ++i) {
-        u32 wv[EW];
-        HIP_TRY(hipMemcpyAsync(wv, pk->d_w + (size_t)pk->public_committed[i] * EW, 32, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        fr_ext_to_be32(wv, buf.data() + 64 + 32 * i);
-    }
+    for (size_t i = 0; i < pk->public_committed.size(); ++i) fr_ext_to_be32(pubw.data() + (size_t)pk->public_committed[i] * EW, buf.data() + 64 + 32 * i);
     uint8_t hsh[32];
     keccak256(buf.data(), buf.size(), hsh);
     u32 cwv[EW], cext[EW];

@@ -72,14 +72,18 @@ struct dvn_points {
 // Default expansion policy (measured on MI355X, tools/gpu_expand_sweep.py, G1 and G2 alike): with the staged sort the
 // one-bucket-set layout wins 10-30 % from 2^15 points up -- window 16 below 2^18, 17 below 2^20, 20 from there (18, 19 and
 // 21 lose: their top window holds 2-7 bits of a 254-bit scalar and piles a quarter of all entries into a few buckets).
+// Small sets (2^10 .. 2^15 points: commitment bases, small keys) take it too, with 15-bit windows: their cost is the latency of
+// the bucket reduction, and ONE bucket set reduced by marginal sums needs 0.31-0.41 ms where the per-window running sums of the
+// plain layout need 0.5-0.6 (tools/gpu_small_msm.py).
+constexpr u32 DVN_EXPAND_MIN_LOG = 10;
 // A set is left plain when its table would exceed DVN_MSM_EXPAND_MAX_GB (default 16 GiB; HBM is 288 GB, a Groth16 key has
 // five sets).  DVN_MSM_EXPAND=0 disables expansion globally.
 static inline void expand_plan(size_t n, u32 scalar_bits, size_t point_bytes, u32* c, u32* nexp) {
     static const int enabled = []() { const char* v = getenv("DVN_MSM_EXPAND"); return (v && v[0] == '0') ? 0 : 1; }();
     static const size_t max_bytes = []() { const char* v = getenv("DVN_MSM_EXPAND_MAX_GB"); return (size_t)(v ? atoi(v) : 16) << 30; }();
     *c = 0; *nexp = 1;
-    if (!enabled || n < ((size_t)1 << 15)) return;
-    u32 cc = n >= ((size_t)1 << 20) ? 20 : n >= ((size_t)1 << 18) ? 17 : 16;
+    if (!enabled || n < ((size_t)1 << DVN_EXPAND_MIN_LOG)) return;
+    u32 cc = n >= ((size_t)1 << 20) ? 20 : n >= ((size_t)1 << 18) ? 17 : n >= ((size_t)1 << 15) ? 16 : 15;
     // a top row of only a few bits (255 = 15 * 17 + 0: nothing but carries; 377 = 22 * 17 + 3) piles a large share of all entries
     // into a handful of buckets: take the next window size whose top row holds at least 8 bits
     while (scalar_bits % cc < 8 && cc < 21) ++cc;

@@ -388,7 +388,8 @@ template <class HG> static typename HG::X bitsum_combine(const u32* h, u32 kh, u
     return acc;
 }
 static inline bool use_expanded(const dvn_points* pts, size_t n) {
-    return pts->expand_c != 0 && n >= ((size_t)1 << 15) && n * 4 >= pts->n;
+    static const u32 min_log = [] { const char* e = getenv("DVN_MSM_EXPANDED_MIN_LOG"); const int v = e ? atoi(e) : 0; return (u32)(v >= 8 && v <= 20 ? v : DVN_EXPAND_MIN_LOG); }();
+    return pts->expand_c != 0 && n >= ((size_t)1 << min_log) && n * 4 >= pts->n;
 }
 template <class Cv>
 static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars, uint32_t flags,
@@ -677,7 +678,7 @@ static int32_t msm_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_
 // (this is what one GPU of a sharded prover computes).  An expanded set (row w = 2^(c w) P) is shared by ENTRY COUNT: its
 // nexp * n (row, point) entries, in row-major order, are cut into `world` equal ranges -- 13 rows over 8 GPUs are 1.625 rows
 // each, not 2 / 2 / 2 / 2 / 2 / 1 / 1 / 1 -- a rank runs the rows its range touches with the entries outside the range
-// masked to zero digits.  A set too small to be expanded (< 2^15 points: microseconds of work) is computed whole by rank 0,
+// masked to zero digits.  A set too small to be expanded (< 2^10 points: microseconds of work) is computed whole by rank 0,
 // the other ranks contribute the point at infinity.
 template <class Cv>
 static int32_t msm_share_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const u32* d_scalars, u32 rank, u32 world, MsmLane** lane_out,

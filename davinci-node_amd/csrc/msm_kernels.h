@@ -850,7 +850,7 @@ __global__ __launch_bounds__(64 * Lanes<Cv>::LPP) void k_window_finalize(const u
     (void)nwin_local;
 }
 
-// ---- bucket reduction of ONE large bucket set (expanded point sets: 2^15 .. 2^20 buckets), without running sums --------
+// ---- bucket reduction of ONE large bucket set (expanded point sets: 2^14 .. 2^20 buckets), without running sums --------
 // sum_b (b + 1) B_b with b = hi * RL + lo (RL = 2^kl columns, RH = nb / RL rows) splits into two plain marginal sums,
 //     RL * sum_hi hi * R_hi  +  sum_lo (lo + 1) * C_lo,      R_hi = sum_lo B[hi][lo],   C_lo = sum_hi B[hi][lo],
 // and a weighted sum over <= 1024 marginals splits by the bits of the weight into plain subset sums,

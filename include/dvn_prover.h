@@ -84,8 +84,8 @@ int32_t dvn_points_upload_g2(dvn_ctx* ctx, const uint64_t* xy_mont, size_t n, dv
 int32_t dvn_points_synthetic_g1(dvn_ctx* ctx, uint64_t seed, size_t n, dvn_points** out);
 int32_t dvn_points_synthetic_g2(dvn_ctx* ctx, uint64_t seed, size_t n, dvn_points** out);
 /* (Re)build the set as an expanded table for window size window_bits in [11, 21] (row w = 2^(window_bits * w) * P_i,
- * 254 / window_bits + 1 rows), or collapse it back to a plain set with 0.  By default every set of >= 2^15 points, G1 or
- * G2, is expanded at upload (window 16 below 2^18 points, 17 below 2^20, 20 from there) unless its table would exceed
+ * 254 / window_bits + 1 rows), or collapse it back to a plain set with 0.  By default every set of >= 2^10 points, G1 or
+ * G2, is expanded at upload (window 15 below 2^15 points, 16 below 2^18, 17 below 2^20, 20 from there) unless its table would exceed
  * DVN_MSM_EXPAND_MAX_GB (16 GiB); DVN_MSM_EXPAND=0 turns the default off. */
 int32_t dvn_points_set_expanded(dvn_ctx* ctx, dvn_points* pts, uint32_t window_bits);
 /* Synthetic scalar vector written to DEVICE memory d_out (n x 4 uint64, gnark Montgomery form): kind 0 =
@@ -208,7 +208,7 @@ int32_t dvn_groth16_prove(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witn
  * equal range of the (row, point) entries of every expanded key set, so 13 rows over 8 ranks are 1.625 rows each -- and
  * returns 72 uint64 of partial results (Jacobian images of the A, B1, K, Z partial sums, 12 each, and of B2, 24); the ranks
  * all-gather the 576-byte buffers (RCCL), and dvn_groth16_prove_combine (host only) adds them and assembles the proof.  A
- * key set too small to be expanded (< 2^15 points) is computed whole by rank 0. */
+ * key set too small to be expanded (< 2^10 points) is computed whole by rank 0. */
 int32_t dvn_groth16_prove_shard(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* witness, uint32_t flags,
                                 uint32_t rank, uint32_t world, uint64_t partial_out[72]);
 int32_t dvn_groth16_prove_combine(const dvn_groth16_pk* pk, const uint64_t* partials /* world x 72 */, uint32_t world,
