@@ -241,3 +241,33 @@ extern "C" int hc_raw_op(int field, int op, const uint32_t* a, const uint32_t* b
         default: raw_op<Fp377Cfg>(op, a, b, r); return Fp377Cfg::NL;
     }
 }
+
+// ---- the one-bucket-set reduction, host half (host_fast.h bitsum_combine_pieces) ------------------------------------------------
+// The pieces are formed here exactly as the device kernels define them -- row / column sums of the bucket matrix (k_marginal_level),
+// subset sums by weight bit in spans of BITSUM_SPAN (k_marginal_bitsums: bit j of hi for the rows, bit j of lo + 1 for the columns)
+// -- over B_b = [ks[b]] G on BN254 G1, then combined.  out: sum_b (b + 1) B_b as a G1Jac image (X | Y | Z, Montgomery words).
+#include <vector>
+extern "C" void hc_bitsum_reduction(uint32_t kh, uint32_t kl, const uint32_t* ks, uint64_t* out_jac) {
+    typedef dvn_host::HG1 HG;
+    typedef dvn_host::OpsFq O;
+    const uint32_t RH = 1u << kh, RL = 1u << kl, SPAN = dvn_host::BITSUM_SPAN;
+    const HG::X G{O::one(), O::add(O::one(), O::one()), O::one(), O::one()};                     // (1, 2)
+    std::vector<HG::X> R(RH, HG::infinity()), Cs(RL, HG::infinity());
+    for (uint32_t hi = 0; hi < RH; ++hi)
+        for (uint32_t lo = 0; lo < RL; ++lo) {
+            const HG::X B = HG::mul_scalar_n(G, &ks[(size_t)hi * RL + lo], 1);
+            R[hi] = HG::add(R[hi], B); Cs[lo] = HG::add(Cs[lo], B);
+        }
+    const uint32_t sr = (RH + SPAN - 1) / SPAN, sc = (RL + SPAN - 1) / SPAN;
+    std::vector<HG::X> P(dvn_host::bitsum_pieces(kh, kl), HG::infinity());
+    for (uint32_t j = 0; j < kh; ++j)
+        for (uint32_t s = 0; s < sr; ++s)
+            for (uint32_t e = s * SPAN; e < RH && e < (s + 1) * SPAN; ++e)
+                if ((e >> j) & 1) P[(size_t)j * sr + s] = HG::add(P[(size_t)j * sr + s], R[e]);
+    for (uint32_t j = 0; j <= kl; ++j)
+        for (uint32_t s = 0; s < sc; ++s)
+            for (uint32_t e = s * SPAN; e < RL && e < (s + 1) * SPAN; ++e)
+                if (((e + 1) >> j) & 1) P[(size_t)kh * sr + (size_t)j * sc + s] = HG::add(P[(size_t)kh * sr + (size_t)j * sc + s], Cs[e]);
+    const HG::X r = dvn_host::bitsum_combine_pieces<HG>([&](size_t i) { return P[i]; }, kh, kl);
+    HG::write_jac(r, out_jac);
+}

@@ -184,6 +184,31 @@ template <class O> struct Group {
         O::store(O::mul(p.x, iz2), out); O::store(O::mul(p.y, zi), out + O::U64S); O::store(O::one(), out + 2 * O::U64S);
     }
 };
+// ---- host half of the one-bucket-set reduction (msm_kernels.h k_marginal_level / k_marginal_bitsums) -----------------------------
+// The device leaves, for the bucket matrix B[hi][lo] (2^kh rows, 2^kl columns, bucket b = hi 2^kl + lo has weight b + 1), plain
+// SUBSET sums of its row sums R_hi and column sums C_lo: for every bit j of the row weight hi the sum of the R_hi with that bit set,
+// for every bit j of the column weight lo + 1 the sum of the C_lo with that bit set -- each in ceil(count / BITSUM_SPAN) pieces
+// (one per workgroup).  Piece order: row bits first (bit-major, pieces of a bit adjacent), then the kl + 1 column bits.
+//   sum_b (b + 1) B_b = 2^kl sum_hi hi R_hi + sum_lo (lo + 1) C_lo = sum_j 2^(kl + j) SR_j + sum_j 2^j SC_j
+constexpr uint32_t BITSUM_SPAN = 512;
+static inline uint32_t bitsum_pieces(uint32_t kh, uint32_t kl) {
+    const uint32_t sr = ((1u << kh) + BITSUM_SPAN - 1) / BITSUM_SPAN, sc = ((1u << kl) + BITSUM_SPAN - 1) / BITSUM_SPAN;
+    return kh * sr + (kl + 1) * sc;
+}
+// piece(i) -> the i-th piece as a group element; MSB first, ~2 (kh + kl) group operations
+template <class HG, class Piece> static inline typename HG::X bitsum_combine_pieces(Piece piece, uint32_t kh, uint32_t kl) {
+    const uint32_t sr = ((1u << kh) + BITSUM_SPAN - 1) / BITSUM_SPAN, sc = ((1u << kl) + BITSUM_SPAN - 1) / BITSUM_SPAN;
+    const size_t col0 = (size_t)kh * sr;
+    typename HG::X acc = HG::infinity();
+    for (int e = (int)(kl + kh); e >= 0; --e) {
+        acc = HG::dbl(acc);
+        if (e >= (int)kl && e - (int)kl < (int)kh)
+            for (uint32_t s = 0; s < sr; ++s) acc = HG::add(acc, piece((size_t)(e - kl) * sr + s));
+        if (e <= (int)kl)
+            for (uint32_t s = 0; s < sc; ++s) acc = HG::add(acc, piece(col0 + (size_t)e * sc + s));
+    }
+    return acc;
+}
 typedef Group<OpsFq> HG1;
 typedef Group<OpsFq2> HG2;
 

@@ -367,25 +367,10 @@ static int32_t msm_windows(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, size
 // width pts->expand_c, all accumulated into ONE bucket set.  host_sum receives ONE internal xyzz image: the partial
 // result of these windows, window weights included (partial results of different window ranges simply add up).
 // --------------------------------------------------------------------------------------------------------------------
-// Pieces the reduction of an expanded bucket set leaves for the host (k_marginal_bitsums): sr pieces for each of the kh bits of
-// the row weight, then sc pieces for each of the kl + 1 bits of the column weight.
-static inline u32 bitsum_pieces(u32 kh, u32 kl) {
-    const u32 sr = ((1u << kh) + BITSUM_SPAN - 1) / BITSUM_SPAN, sc = ((1u << kl) + BITSUM_SPAN - 1) / BITSUM_SPAN;
-    return kh * sr + (kl + 1) * sc;
-}
-// sum_j 2^(kl + j) SR_j + sum_j 2^j SC_j over those pieces, MSB first (~2 c group operations on the host)
+// Pieces the reduction of an expanded bucket set leaves for the host (k_marginal_bitsums): layout and combine in host_fast.h
+using dvn_host::bitsum_pieces;
 template <class HG> static typename HG::X bitsum_combine(const u32* h, u32 kh, u32 kl, u32 xw) {
-    const u32 sr = ((1u << kh) + BITSUM_SPAN - 1) / BITSUM_SPAN, sc = ((1u << kl) + BITSUM_SPAN - 1) / BITSUM_SPAN;
-    const u32* hc = h + (size_t)kh * sr * xw;
-    typename HG::X acc = HG::infinity();
-    for (int e = (int)(kl + kh); e >= 0; --e) {
-        acc = HG::dbl(acc);
-        if (e >= (int)kl && e - (int)kl < (int)kh)
-            for (u32 s = 0; s < sr; ++s) acc = HG::add(acc, HG::load_device(h + ((size_t)(e - kl) * sr + s) * xw));
-        if (e <= (int)kl)
-            for (u32 s = 0; s < sc; ++s) acc = HG::add(acc, HG::load_device(hc + ((size_t)e * sc + s) * xw));
-    }
-    return acc;
+    return dvn_host::bitsum_combine_pieces<HG>([&](size_t i) { return HG::load_device(h + i * xw); }, kh, kl);
 }
 static inline bool use_expanded(const dvn_points* pts, size_t n) {
     static const u32 min_log = [] { const char* e = getenv("DVN_MSM_EXPANDED_MIN_LOG"); const int v = e ? atoi(e) : 0; return (u32)(v >= 8 && v <= 20 ? v : DVN_EXPAND_MIN_LOG); }();

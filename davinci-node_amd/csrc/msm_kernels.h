@@ -17,6 +17,7 @@
 //   host          Horner combine of the <= 32 window sums (O(254) group operations)
 #pragma once
 #include "bn254_curve.h"
+#include "host_fast.h"
 #include "fp2_paired.h"
 
 namespace dvn {
@@ -885,7 +886,7 @@ __global__ __launch_bounds__(MARG_THREADS * Lanes<Cv>::LPP) void k_marginal_leve
 // k_marginal_bitsums: the subset sums of the marginals, BITSUM_SPAN marginals per block.  Blocks [0, kh * sr) take bit
 // j = block / sr of the row index hi (weight of R_hi), the next (kl + 1) * sc blocks bit j of lo + 1 (weight of C_lo);
 // sr = ceil(RH / BITSUM_SPAN), sc = ceil(RL / BITSUM_SPAN).  out[block] receives the piece.
-constexpr u32 BITSUM_THREADS = 256, BITSUM_SPAN = 512;
+constexpr u32 BITSUM_THREADS = 256, BITSUM_SPAN = dvn_host::BITSUM_SPAN;      // marginals per piece: the host's combine uses the same span
 template <class Cv>
 __global__ __launch_bounds__(BITSUM_THREADS * Lanes<Cv>::LPP) void k_marginal_bitsums(const u32* __restrict__ marg, u32* __restrict__ out, u32 nb, u32 kl) {
     typedef typename Cv::X X;

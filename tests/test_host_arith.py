@@ -203,3 +203,21 @@ def test_lazy_accumulator_chain_with_signs(hc, opy, orc):
             pt = aff[e & 0x7fffffff]
             acc = o.g1_add(acc, o.g1_neg(pt) if e >> 31 else pt)
         assert [int(v) for v in r] == o.g1_to_limbs(acc), idx[:8]
+
+
+@pytest.mark.parametrize("kh,kl", [(1, 1), (3, 2), (5, 5), (10, 3), (2, 10)])
+def test_one_bucket_set_reduction_host_half(hc, opy, orc, kh, kl):
+    """sum_b (b + 1) B_b through row / column sums, subset sums by weight bit and the host's combine (host_fast.h
+    bitsum_combine_pieces, the code msm_collect runs on the device's pieces) equals the plain weighted sum: buckets B_b = [k_b] G with
+    zeros, ones and random multipliers; 2^10 rows or columns give two pieces per bit."""
+    o = opy
+    nb = 1 << (kh + kl)
+    rng = np.random.default_rng(kh * 100 + kl)
+    ks = rng.integers(0, 1 << 20, size=nb, dtype=np.uint32)
+    ks[::7] = 0; ks[1::11] = 1
+    out = np.zeros(12, dtype=np.uint64)
+    hc.hc_bitsum_reduction(C.c_uint32(kh), C.c_uint32(kl), p(ks), out.ctypes.data_as(C.POINTER(C.c_uint64)))
+    total = sum((b + 1) * int(k) for b, k in enumerate(ks)) % o.R
+    g = np.array([o.limbs(o.to_mont(1, o.P)) + o.limbs(o.to_mont(2, o.P))], dtype=np.uint64)
+    want = orc.msm_g1(g, np.array([o.limbs(o.to_mont(total, o.R))], dtype=np.uint64))
+    assert (out[:8] == np.asarray(want).reshape(-1)[:8]).all()
