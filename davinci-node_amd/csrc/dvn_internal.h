@@ -82,14 +82,8 @@ static inline void expand_plan(size_t n, u32 scalar_bits, size_t point_bytes, u3
     static const int enabled = []() { const char* v = getenv("DVN_MSM_EXPAND"); return (v && v[0] == '0') ? 0 : 1; }();
     static const size_t max_bytes = []() { const char* v = getenv("DVN_MSM_EXPAND_MAX_GB"); return (size_t)(v ? atoi(v) : 16) << 30; }();
     *c = 0; *nexp = 1;
-    if (!enabled || n < ((size_t)1 << DVN_EXPAND_MIN_LOG)) return;
-    u32 cc = n >= ((size_t)1 << 20) ? 20 : n >= ((size_t)1 << 18) ? 17 : n >= ((size_t)1 << 15) ? 16 : 15;
-    // a top row of only a few bits (255 = 15 * 17 + 0: nothing but carries; 377 = 22 * 17 + 3) piles a large share of all entries
-    // into a handful of buckets: take the next window size whose top row holds at least 8 bits
-    while (scalar_bits % cc < 8 && cc < 21) ++cc;
-    const u32 rows = scalar_bits / cc + 1;
-    if ((size_t)rows * n * point_bytes > max_bytes || (size_t)rows * n >= ((size_t)1 << 31)) return;
-    *c = cc; *nexp = rows;
+    if (!enabled) return;
+    dvn_host::expand_plan_pure(n, scalar_bits, point_bytes, DVN_EXPAND_MIN_LOG, max_bytes, c, nexp);
 }
 struct dvn_domain {
     int suite = 0;            // 0 = BN254 Fr, 1 = BLS12-377 Fr

@@ -271,3 +271,9 @@ extern "C" void hc_bitsum_reduction(uint32_t kh, uint32_t kl, const uint32_t* ks
     const HG::X r = dvn_host::bitsum_combine_pieces<HG>([&](size_t i) { return P[i]; }, kh, kl);
     HG::write_jac(r, out_jac);
 }
+
+// launch planning (host_fast.h)
+extern "C" uint32_t hc_ntt_pass_plan(uint32_t log_n, uint32_t kmax, int dif, uint32_t* ks) { return dvn_host::ntt_pass_plan(log_n, kmax, dif != 0, ks); }
+extern "C" void hc_expand_plan(uint64_t n, uint32_t scalar_bits, uint64_t point_bytes, uint32_t min_log, uint64_t max_bytes, uint32_t* c, uint32_t* nexp) {
+    dvn_host::expand_plan_pure((size_t)n, scalar_bits, (size_t)point_bytes, min_log, (size_t)max_bytes, c, nexp);
+}

@@ -184,6 +184,38 @@ template <class O> struct Group {
         O::store(O::mul(p.x, iz2), out); O::store(O::mul(p.y, zi), out + O::U64S); O::store(O::one(), out + 2 * O::U64S);
     }
 };
+// ---- launch planning (pure functions: also compiled into the CPU test library) ---------------------------------------------------
+// Stage counts of the passes of a 2^log_n transform in EXECUTION order (dif: stages ascending, else descending): ceil(log_n / kmax)
+// passes of nearly equal counts.  The pass that holds the transform's last two stages (the last pass of DIF, the first of DIT) gets
+// an even count when there is a way -- a swap with an even pass, or one stage handed to a neighbour -- so that those two stages form
+// one radix-4 round (the multiplication-free one on plain twiddle tables).  Returns the number of passes (<= 16).
+static inline uint32_t ntt_pass_plan(uint32_t log_n, uint32_t kmax, bool dif, uint32_t ks[16]) {
+    const uint32_t npass = (log_n + kmax - 1) / kmax;
+    const uint32_t base = log_n / npass, rem = log_n % npass;
+    for (uint32_t p = 0; p < npass; ++p) ks[p] = base + (p < rem ? 1 : 0);
+    if (npass > 1) {
+        const uint32_t end = dif ? npass - 1 : 0;
+        if (ks[end] & 1) {
+            bool done = false;
+            for (uint32_t p = 0; p < npass && !done; ++p) if (!(ks[p] & 1)) { const uint32_t t = ks[p]; ks[p] = ks[end]; ks[end] = t; done = true; }
+            for (uint32_t p = 0; p < npass && !done; ++p) if (p != end && ks[p] < kmax && ks[end] > 2) { ++ks[p]; --ks[end]; done = true; }
+        }
+    }
+    return npass;
+}
+// Window size and row count of the expanded table of an n-point set (0 / 1: the set stays plain); see dvn_internal.h expand_plan
+// for the measurements behind the numbers.  min_log: smallest expanded set; max_bytes: table size limit.
+static inline void expand_plan_pure(size_t n, uint32_t scalar_bits, size_t point_bytes, uint32_t min_log, size_t max_bytes, uint32_t* c, uint32_t* nexp) {
+    *c = 0; *nexp = 1;
+    if (n < ((size_t)1 << min_log)) return;
+    uint32_t cc = n >= ((size_t)1 << 20) ? 20 : n >= ((size_t)1 << 18) ? 17 : n >= ((size_t)1 << 15) ? 16 : 15;
+    // a top row of only a few bits (255 = 15 * 17 + 0: nothing but carries; 377 = 22 * 17 + 3) piles a large share of all entries
+    // into a handful of buckets: take the next window size whose top row holds at least 8 bits
+    while (scalar_bits % cc < 8 && cc < 21) ++cc;
+    const uint32_t rows = scalar_bits / cc + 1;
+    if ((size_t)rows * n * point_bytes > max_bytes || (size_t)rows * n >= ((size_t)1 << 31)) return;
+    *c = cc; *nexp = rows;
+}
 // ---- host half of the one-bucket-set reduction (msm_kernels.h k_marginal_level / k_marginal_bitsums) -----------------------------
 // The device leaves, for the bucket matrix B[hi][lo] (2^kh rows, 2^kl columns, bucket b = hi 2^kl + lo has weight b + 1), plain
 // SUBSET sums of its row sums R_hi and column sums C_lo: for every bit j of the row weight hi the sum of the R_hi with that bit set,

@@ -156,21 +156,9 @@ template <class S> static int32_t ntt_device(dvn_ctx* ctx, const dvn_domain* d, 
     RoctxRange rr(inverse ? "dvn:ntt_inverse" : "dvn:ntt_forward");
     const u32 log_n = d->log_n;
     static const u32 kmax = [] { const char* e = getenv("DVN_NTT_KMAX"); const int v = e ? atoi(e) : 0; return (u32)(v >= 2 && v <= 11 ? v : NTT_KMAX); }();
-    const u32 npass = (log_n + kmax - 1) / kmax;
-    const u32 base = log_n / npass, rem = log_n % npass;
-    // stage counts per pass in execution order.  The pass that holds the transform's last two stages (the last pass of DIF, the
-    // first of DIT) gets an even count when there is a choice, so that those two stages form one radix-4 round.
+    // stage counts per pass in execution order (host_fast.h: the pass with the transform's last two stages gets an even count)
     u32 ks[16];
-    for (u32 p = 0; p < npass; ++p) ks[p] = base + (p < rem ? 1 : 0);
-    if (npass > 1) {
-        const u32 end = decimation == DVN_DIF ? npass - 1 : 0;
-        if (ks[end] & 1) {
-            // swap with a pass of even count; if every pass is odd, hand one stage over to a neighbour
-            bool done = false;
-            for (u32 p = 0; p < npass && !done; ++p) if (!(ks[p] & 1)) { const u32 t = ks[p]; ks[p] = ks[end]; ks[end] = t; done = true; }
-            for (u32 p = 0; p < npass && !done; ++p) if (p != end && ks[p] < kmax && ks[end] > 2) { ++ks[p]; --ks[end]; done = true; }
-        }
-    }
+    const u32 npass = dvn_host::ntt_pass_plan(log_n, kmax, decimation == DVN_DIF, ks);
     // the butterfly network absorbs the coset scaling where its shape allows (DIT: a scaling of the input, DIF: of the output)
     const bool merged = coset && ((!inverse && decimation == DVN_DIT) || (inverse && decimation == DVN_DIF));
     const u32* tw = inverse ? (merged ? d->tw_inv_c : d->tw_inv) : (merged ? d->tw_fwd_c : d->tw_fwd);

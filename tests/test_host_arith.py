@@ -221,3 +221,45 @@ def test_one_bucket_set_reduction_host_half(hc, opy, orc, kh, kl):
     g = np.array([o.limbs(o.to_mont(1, o.P)) + o.limbs(o.to_mont(2, o.P))], dtype=np.uint64)
     want = orc.msm_g1(g, np.array([o.limbs(o.to_mont(total, o.R))], dtype=np.uint64))
     assert (out[:8] == np.asarray(want).reshape(-1)[:8]).all()
+
+
+def test_ntt_pass_plan(hc):
+    """Stage counts of the passes of a transform: they add up to log_n, none exceeds the tile limit, and the pass that holds the last
+    two stages (last of DIF, first of DIT) has an even count whenever the transform has more than one pass."""
+    ks = (C.c_uint32 * 16)()
+    for kmax in (8, 10, 11):
+        for log_n in range(1, 28):
+            for dif in (1, 0):
+                npass = hc.hc_ntt_pass_plan(log_n, kmax, dif, ks)
+                got = list(ks[:npass])
+                assert npass == -(-log_n // kmax) and sum(got) == log_n and max(got) <= kmax and min(got) >= 1, (log_n, kmax, dif, got)
+                if npass > 1 and kmax % 2 == 0:          # (an odd limit can leave every pass full and odd: 11 + 11)
+                    end = got[-1] if dif else got[0]
+                    assert end % 2 == 0, (log_n, kmax, dif, got)
+    hc.hc_ntt_pass_plan(24, 10, 1, ks); assert list(ks[:3]) == [8, 8, 8]
+    hc.hc_ntt_pass_plan(20, 10, 1, ks); assert list(ks[:2]) == [10, 10]
+    hc.hc_ntt_pass_plan(21, 10, 1, ks); assert list(ks[:3]) == [8, 7, 6]
+    hc.hc_ntt_pass_plan(21, 10, 0, ks); assert list(ks[:3]) == [6, 8, 7]
+
+
+def test_expand_plan(hc):
+    """Window size of a set's expanded table: 15 bits from 2^10 points, 16 from 2^15, 17 from 2^18, 20 from 2^20 -- moved up to the next
+    size whose top row holds at least 8 bits of the scalar (254-, 253-, 255- and 377-bit fields) -- and no table above the size limit."""
+    c, rows = C.c_uint32(), C.c_uint32()
+    def plan(n, bits, pb=64, min_log=10, max_bytes=16 << 30):
+        hc.hc_expand_plan(C.c_uint64(n), bits, C.c_uint64(pb), min_log, C.c_uint64(max_bytes), C.byref(c), C.byref(rows))
+        return c.value, rows.value
+    assert plan(1023, 254) == (0, 1)
+    assert plan(1 << 10, 254) == (15, 17) and plan((1 << 15) - 1, 254) == (15, 17)
+    assert plan(1 << 15, 254) == (16, 16) and plan(1 << 18, 254) == (17, 15) and plan(1 << 20, 254) == (20, 13) and plan(1 << 24, 254) == (20, 13)
+    assert plan(1 << 14, 255) == (16, 16)            # 255 = 15 * 17: a 15-bit window would leave the top row nothing but carries
+    assert plan(1 << 18, 255) == (19, 14)            # 255 % 17 = 0, 255 % 18 = 3 -> 19
+    assert plan(1 << 18, 377, 192) == (18, 21)       # 377 = 22 * 17 + 3
+    for bits in (253, 254, 255, 377):
+        for ln in range(10, 25):
+            cc, rr = plan(1 << ln, bits)
+            if cc:
+                assert bits % cc >= 8 or cc == 21, (bits, ln, cc)
+                assert rr == bits // cc + 1
+    assert plan(1 << 24, 254, 128, 10, 16 << 30) == (0, 1)      # 13 rows x 2^24 x 128 B = 26 GiB: stays plain
+    assert plan(1 << 27, 254) == (0, 1)                          # 13 x 2^27 entry positions do not fit 31 bits
