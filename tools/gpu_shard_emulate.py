@@ -1,6 +1,6 @@
 """Per-rank cost of the window-sharded MSM at world sizes 1..8, emulated on ONE GPU: this process plays rank 0 of N
-(its slice of the windows); the all-gather is replaced by a local copy, so the figure is the GPU + host side of a
-step without the RCCL latency."""
+(its share of the entries); the all-gather is replaced by a local copy, so the figure is the GPU + host side of a
+step without the RCCL latency.  Arguments: how many steps to keep in flight (default 2; several values = several tables)."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,14 +20,18 @@ class FakeDist:
 ctx = pkg.Context(0)
 n = 1 << 22
 pts = ctx.synthetic_g1(0xDA71C1, n); d = ctx.synthetic_scalars(1, 0, n)
-for world in (1, 2, 4, 8):
-    pipe = sh.ShardedMsmPipeline(ctx, pts, n, 0, world, FakeDist(), "cpu")
-    steps, warm = 40, 5
-    pipe.submit(d)
-    for k in range(warm + steps):
-        if k == warm:
-            t0 = time.time()
-        pipe.submit(d); pipe.collect()
-    pipe.collect()
-    dt = (time.time() - t0) / steps
-    print(f"world {world}: rank-0 step {dt*1e3:.3f} ms -> {n/dt/1e6:.0f} Mscalar/s (ideal {world}x of world 1)", flush=True)
+depths = [int(a) for a in sys.argv[1:]] or [2]
+for depth in depths:
+    for world in (1, 2, 4, 8):
+        pipe = sh.ShardedMsmPipeline(ctx, pts, n, 0, world, FakeDist(), "cpu")
+        steps, warm = 40, 5
+        for _ in range(depth - 1):
+            pipe.submit(d)
+        for k in range(warm + steps):
+            if k == warm:
+                t0 = time.time()
+            pipe.submit(d); pipe.collect()
+        while pipe.in_flight():
+            pipe.collect()
+        dt = (time.time() - t0) / steps
+        print(f"{depth} steps in flight, world {world}: rank-0 step {dt*1e3:.3f} ms -> {n/dt/1e6:.0f} Mscalar/s (ideal {world}x of world 1)", flush=True)
