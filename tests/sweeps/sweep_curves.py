@@ -1,10 +1,10 @@
 """Differential sweep of the BLS12-377 / BLS12-381 / BW6-761 instantiations against the big-integer oracle
 (oracle/curves_py.py): NTT in all eight modes and ragged computeH at log n = 3..10 with random seeds, and G1 MSMs over
 device-generated progressions against the closed form sum s_i (P0 + i D) = (sum s_i) P0 + (sum i s_i) D at 2^10..2^15 points.
-Usage: python tools/gpu_fuzz_curves.py [seconds]"""
+Usage: python tests/sweeps/sweep_curves.py [seconds]"""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 pkg = g.load_package()

@@ -1,9 +1,9 @@
 """Differential sweep of the synthetic Groth16 prover against the oracle's trapdoor closed form at random constraint counts
 (not powers of two), public-input counts and blinding factors; every few cases also the shares of worlds 2..5 combined.
-Usage: python tools/gpu_fuzz_groth16.py [seconds]"""
+Usage: python tests/sweeps/sweep_groth16.py [seconds]"""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 pkg = g.load_package()

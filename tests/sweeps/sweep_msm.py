@@ -1,9 +1,9 @@
 """Differential sweep of the G1 / G2 MSM against the C oracle at sizes around the tile, segment and policy boundaries, with
 scalar vectors built to stress the signed-digit carries (every window at half, r - 1, zeros, one hot bucket).
-Usage: python tools/gpu_fuzz_msm.py [seconds]   (default 60; stops after the time budget, prints the number of cases)"""
+Usage: python tests/sweeps/sweep_msm.py [seconds]   (default 60; stops after the time budget, prints the number of cases)"""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 pkg = g.load_package()

@@ -1,8 +1,8 @@
 """Differential sweep of the NTT (all eight modes) and computeH (ragged lengths) against the C oracle at log n = 1..17.
-Usage: python tools/gpu_fuzz_ntt.py [seconds]"""
+Usage: python tests/sweeps/sweep_ntt.py [seconds]"""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 pkg = g.load_package()

@@ -1,9 +1,9 @@
 """Differential sweep of the shared MSM (`dvn_msm_g1_share_*`): random sizes, worlds 1..16 and window sizes; the sum of the
 shares must equal the C oracle's MSM.  Covers plain sets (whole-window shares) and expanded sets (entry-count shares).
-Usage: python tools/gpu_fuzz_shares.py [seconds]"""
+Usage: python tests/sweeps/sweep_shares.py [seconds]"""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 pkg = g.load_package()
