@@ -117,7 +117,10 @@ int32_t dvn_msm_g1_batched(dvn_ctx* ctx, const dvn_points* pts, size_t off, size
  * ticket; _collect waits for it and writes the result.  With several MSMs in flight the sort and the latency-bound tail of
  * one run under the accumulate kernel of the other (measured +10 % throughput at 2^22, +19 % at 2^20, +52 % at 2^18).
  * Host scalars are copied before _submit returns; DEVICE scalars must stay untouched until _collect.  At most four
- * tickets may be outstanding per context (one per lane). */
+ * tickets may be outstanding per context (one per lane), whichever threads hold them.  The synchronous entry points take their
+ * lanes from the same four (an MSM one, a proof up to four) and FAIL with "too many MSMs in flight" rather than wait when
+ * outstanding tickets leave too few -- the ticket holder may be the calling thread.  Callers that mix tickets and synchronous
+ * calls on several threads collect their tickets first, or give the asynchronous work a context of its own. */
 int32_t dvn_msm_g1_submit(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars_mont,
                           uint32_t flags, int32_t* ticket);
 int32_t dvn_msm_g1_collect(dvn_ctx* ctx, int32_t ticket, uint64_t out_jac[12]);
