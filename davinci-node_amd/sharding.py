@@ -23,7 +23,8 @@ def exchange_window_sums(local: np.ndarray, nwin: int, world: int, rank: int, di
     import torch
     lo, hi = window_slice(nwin, world, rank)
     assert local.shape == (hi - lo, 16), (local.shape, lo, hi)
-    if world == 1:
+    if dist is None:                                          # one rank without a process group; WITH one the collective runs (rehearsal)
+        assert world == 1
         return local
     per = -(-nwin // world)                                   # ranks own unequal counts when nwin % world != 0: pad
     mine = np.zeros((per, 16), dtype=np.uint64)
@@ -72,7 +73,8 @@ def all_gather_rows(local: np.ndarray, world: int, dist=None, device="cpu") -> n
     """all-gather one fixed-size uint64 row per rank -> (world, len(local))."""
     import torch
     local = np.ascontiguousarray(local, dtype=np.uint64).reshape(-1)
-    if world == 1:
+    if dist is None:                                          # one rank without a process group; WITH one the collective runs (rehearsal)
+        assert world == 1
         return local.reshape(1, -1)
     send = torch.from_numpy(local.view(np.int64)).to(device)
     recv = torch.empty((world * local.size,), dtype=torch.int64, device=device)

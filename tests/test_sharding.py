@@ -140,6 +140,53 @@ def test_bench_two_ranks_extras_prove_the_committed_statetransition_shape():
     assert ex["groth16_replicas_2^20"]["post_solver_proofs_per_s"] > 0
 
 
+_RCCL_ONE_RANK = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+import __graft_entry__ as g
+pkg = g.load_package()
+from davinci_node_amd import sharding
+from oracle import cpu as orc
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+ctx = pkg.Context(0)
+n = 1 << 16
+pts = ctx.synthetic_g1(5, n); d = ctx.synthetic_scalars(3, 0, n)
+want = orc.g1_jac_to_affine(ctx.msm_g1(pts, d, n=n))
+pipe = sharding.ShardedMsmPipeline(ctx, pts, n, 0, 1, dist, "cuda")       # the N > 1 code of bench.py, one rank
+pipe.submit(d); pipe.submit(d)
+a = pipe.collect(); b = pipe.collect()
+assert (orc.g1_jac_to_affine(a) == want).all() and (orc.g1_jac_to_affine(b) == want).all()
+ctx.synchronize(); torch.cuda.synchronize(); dist.barrier()
+t = torch.tensor([1.5], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); assert float(t.item()) == 1.5
+cs = pkg.R1CS(7, 3000, 9, n_committed=100); key = pkg.Groth16Key(ctx, cs, 3); dw = ctx.to_device(cs.witness())
+rs = np.zeros((2, 4), dtype=np.uint64); rs[0, 0], rs[1, 0] = 5, 7
+proof = sharding.sharded_groth16_prove_committed(key, dw, rs[0], rs[1], 0, 1, dist, "cuda")
+single = key.prove_committed(dw, rs[0], rs[1])
+assert all((single[k] == proof[k]).all() for k in ("Ar", "Bs", "Krs", "Commitment", "CommitmentPok"))
+same = torch.from_numpy(np.concatenate([proof["Ar"], proof["Bs"], proof["Krs"]]).view(np.int64)).to("cuda")
+ref = same.clone(); dist.broadcast(ref, 0)
+agree = torch.tensor([int(bool((same == ref).all()))], device="cuda"); dist.all_reduce(agree, op=dist.ReduceOp.MIN); assert int(agree.item()) == 1
+rows = sharding.exchange_window_sums(np.arange(16 * 16, dtype=np.uint64).reshape(16, 16), 16, 1, 0, dist, "cuda")
+assert (rows == np.arange(16 * 16, dtype=np.uint64).reshape(16, 16)).all()
+dist.barrier(); dist.destroy_process_group()
+print("RCCL_ONE_RANK_OK", flush=True)
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_collectives_of_the_sharded_path_with_one_rank():
+    """Every torch.distributed call of the N > 1 path (bench.py, sharding.py) on the real backend, "nccl" = RCCL, with device
+    tensors: process-group init with a device id, barrier, all-gather of int64 views, all-reduce MAX / MIN, broadcast.  RCCL
+    refuses two ranks on one device, so the rehearsal on a one-GPU box is a world of ONE rank; the two-rank runs above cover
+    the exchange logic over gloo.  Own process: the process group must not outlive the test."""
+    import subprocess
+    code = _RCCL_ONE_RANK.format(root=ROOT, port=29400 + os.getpid() % 90)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=200, cwd=ROOT)
+    assert out.returncode == 0 and "RCCL_ONE_RANK_OK" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+
+
 def test_bench_exit_status_reports_failed_extras():
     """Source-level contract of bench.py's N > 1 tail: both failure paths (watchdog, exception in the extras) leave with a
     non-zero status after printing the line, never 0."""
