@@ -187,6 +187,30 @@ def test_rccl_collectives_of_the_sharded_path_with_one_rank():
     assert out.returncode == 0 and "RCCL_ONE_RANK_OK" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
 
 
+@pytest.mark.gpu
+def test_bench_distributed_path_on_rccl_with_one_rank():
+    """`bench.py`'s own N > 1 code (process group on "nccl" = RCCL with a device id, the shared-MSM pipeline with its
+    all-gather on device tensors, max-over-ranks timing, the sharded committed proof and the replica leg of the extras,
+    the final barrier) launched by torch.distributed.run with ONE rank: DVN_BENCH_REHEARSE_DIST=1 makes a world of one take
+    that path.  What a one-GPU box cannot show is an exchange between two devices."""
+    import json
+    import subprocess
+    env = dict(os.environ, DVN_BENCH_REHEARSE_DIST="1", DVN_BENCH_EXTRAS_LIMIT_S="250")
+    env.pop("DVN_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(29300 + os.getpid() % 90), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--log-n", "20", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=290, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["result_checked"] is True and line["value"] > 0
+    assert "shared by entry count" in line["config"]["parallelism"]
+    ex = line["extras"]
+    assert "error" not in ex, ex
+    sh = ex["groth16_sharded_2^20"]
+    assert sh["ranks"] == 1 and sh["all_ranks_same_proof"] is True and sh["equals_single_gpu_proof"] is True
+
+
 def test_bench_exit_status_reports_failed_extras():
     """Source-level contract of bench.py's N > 1 tail: both failure paths (watchdog, exception in the extras) leave with a
     non-zero status after printing the line, never 0."""
