@@ -1,7 +1,7 @@
 """Differential sweep of the BLS12-377 / BLS12-381 / BW6-761 instantiations against the big-integer oracle
 (oracle/curves_py.py): NTT in all eight modes and ragged computeH at log n = 3..10 with random seeds, and G1 MSMs over
 device-generated progressions against the closed form sum s_i (P0 + i D) = (sum s_i) P0 + (sum i s_i) D at 2^10..2^15 points.
-Usage: python tests/sweeps/sweep_curves.py [seconds]"""
+Usage: python tests/sweeps/sweep_curves.py [seconds [seed]]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +11,7 @@ pkg = g.load_package()
 from oracle import curves_py
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
 ctx = pkg.Context(0)
-rng = np.random.default_rng(31337)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 31337)
 suites = [("bls12-377", curves_py.BLS12_377, pkg.Bls12377(ctx)), ("bls12-381", curves_py.BLS12_381, pkg.Bls12381(ctx)),
           ("bw6-761", curves_py.BW6_761, pkg.Bw6761(ctx))]
 t_end = time.time() + budget

@@ -1,6 +1,6 @@
 """Differential sweep of the synthetic Groth16 prover against the oracle's trapdoor closed form at random constraint counts
 (not powers of two), public-input counts and blinding factors; every few cases also the shares of worlds 2..5 combined.
-Usage: python tests/sweeps/sweep_groth16.py [seconds]"""
+Usage: python tests/sweeps/sweep_groth16.py [seconds [seed]]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +12,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 ctx = pkg.Context(0)
 R = o.R
 mont = lambda x: np.array(o.limbs(o.to_mont(x % R, R)), dtype=np.uint64)
-rng = np.random.default_rng(4242)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4242)
 t_end = time.time() + budget
 cases = 0
 while time.time() < t_end:

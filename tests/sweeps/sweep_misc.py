@@ -1,7 +1,7 @@
 """Differential sweep of the entry points around the MSM: `dvn_msm_g1_static` against `dvn_msm_g1` (random sizes, offsets and
 window sizes, alternating large and small calls so the scratch always holds another call's data), `dvn_msm_g1_batched`
 against single MSMs, and the committed Groth16 prover against the oracle's closed form at random shapes.
-Usage: python tests/sweeps/sweep_misc.py [seconds]"""
+Usage: python tests/sweeps/sweep_misc.py [seconds [seed]]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +13,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
 ctx = pkg.Context(0)
 R = o.R
 mont = lambda x: np.array(o.limbs(o.to_mont(x % R, R)), dtype=np.uint64)
-rng = np.random.default_rng(2026)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
 t_end = time.time() + budget
 cases = refused = 0
 while time.time() < t_end:

@@ -1,6 +1,6 @@
 """Differential sweep of the G1 / G2 MSM against the C oracle at sizes around the tile, segment and policy boundaries, with
 scalar vectors built to stress the signed-digit carries (every window at half, r - 1, zeros, one hot bucket).
-Usage: python tests/sweeps/sweep_msm.py [seconds]   (default 60; stops after the time budget, prints the number of cases)"""
+Usage: python tests/sweeps/sweep_msm.py [seconds [seed]]   (default 60; stops after the time budget, prints the number of cases)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,7 +17,7 @@ def special(c):
     half = sum(1 << (c * w + c - 1) for w in range(254 // c + 1))
     return [R - 1, half % R, (half - 1) % R, (1 << 253), 1, 0, (1 << c) - 1, 1 << (c - 1), (1 << (c - 1)) + 1]
 sizes = sorted({max(1, b + d) for b in (1, 64, 128, 1 << 10, 1 << 13, 1 << 14, 1 << 15, 1 << 16, 1 << 17, 1 << 18) for d in (-1, 0, 1)} | {3, 100003, 50021})
-rng = np.random.default_rng(12345)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 t_end = time.time() + budget
 cases = 0
 for rnd in range(1000):

@@ -1,5 +1,5 @@
 """Differential sweep of the NTT (all eight modes) and computeH (ragged lengths) against the C oracle at log n = 1..17.
-Usage: python tests/sweeps/sweep_ntt.py [seconds]"""
+Usage: python tests/sweeps/sweep_ntt.py [seconds [seed]]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,7 @@ pkg = g.load_package()
 from oracle import cpu as orc
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 ctx = pkg.Context(0)
-rng = np.random.default_rng(99)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 99)
 doms = {}
 t_end = time.time() + budget
 cases = 0

@@ -1,6 +1,6 @@
 """Differential sweep of the shared MSM (`dvn_msm_g1_share_*`): random sizes, worlds 1..16 and window sizes; the sum of the
 shares must equal the C oracle's MSM.  Covers plain sets (whole-window shares) and expanded sets (entry-count shares).
-Usage: python tests/sweeps/sweep_shares.py [seconds]"""
+Usage: python tests/sweeps/sweep_shares.py [seconds [seed]]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +10,7 @@ pkg = g.load_package()
 from oracle import cpu as orc
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 ctx = pkg.Context(0)
-rng = np.random.default_rng(777)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 777)
 t_end = time.time() + budget
 cases = 0
 while time.time() < t_end:

@@ -2,7 +2,7 @@
 computeH, proofs from ONE shared key and from a committed key -- and every result is compared with the value the same call
 returned single-threaded (itself checked against the oracle first).  The header promises that every function is thread-safe.
 Only synchronous entry points: outstanding tickets of the asynchronous ones take lanes away from them by contract.
-Usage: python tests/sweeps/sweep_threads.py [seconds]"""
+Usage: python tests/sweeps/sweep_threads.py [seconds [seed]]"""
 import os, sys, time, threading
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -38,7 +38,7 @@ assert list(wantc["Krs"]) == o.g1_to_limbs(ec["Krs"]) and list(wantc["Commitment
 errors, counts = [], [0] * 8
 t_end = time.time() + budget
 def worker(i):
-    rng = np.random.default_rng(1000 + i)
+    rng = np.random.default_rng((int(sys.argv[2]) if len(sys.argv) > 2 else 1000) + i)
     try:
         while time.time() < t_end and not errors:
             op = int(rng.integers(0, 8)); k = int(rng.integers(0, 4))
