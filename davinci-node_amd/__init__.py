@@ -11,5 +11,5 @@ The directory name contains a dash, so import it through ``__graft_entry__.load_
 from . import sharding  # noqa: F401
 from .binding import (  # noqa: F401
     DvnError, Context, Points, Domain, lib_path, load_library, build_library,
-    DIF, DIT, R1CS, Groth16Key, Bls12377, Bls12381, Bw6761, KzgSetup, ImportedKey, LoadedKey, prove_multi, prove_committed_multi, msm_g1_multi, gnark_pk_scan,
+    DIF, DIT, R1CS, Groth16Key, Bls12377, Bls12381, Bw6761, KzgSetup, ImportedKey, LoadedKey, prove_multi, prove_committed_multi, msm_g1_multi, Comm, gnark_pk_scan,
 )

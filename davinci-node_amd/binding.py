@@ -127,6 +127,7 @@ def load_library():
         "dvn_groth16_vk_export": (i32, [vp, vp, sz, C.POINTER(sz)]),
         "dvn_groth16_pk_import": (i32, [vp, vp, C.POINTER(vp)]),
         "dvn_groth16_prove_solved": (i32, [vp, vp, vp, vp, vp, vp, sz, vp, vp, vp]),
+        "dvn_groth16_prove_solved_shard": (i32, [vp, vp, vp, vp, vp, vp, sz, u32, u32, vp]),
         "dvn_groth16_pk_export_arrays": (i32, [vp, vp, C.c_int, vp, sz, C.POINTER(sz)]),
         "dvn_bls12377_groth16_pk_import": (i32, [vp, vp, C.POINTER(vp)]),
         "dvn_bls12377_groth16_prove_solved": (i32, [vp, vp, vp, vp, vp, vp, sz, vp, vp, vp]),
@@ -171,6 +172,10 @@ def load_library():
         "dvn_msm_g1_share_collect": (i32, [vp, i32, vp]),
         "dvn_msm_g1_sum": (i32, [vp, u32, vp]),
         "dvn_msm_g1_multi": (i32, [vp, vp, u32, sz, sz, vp, vp]),
+        "dvn_comm_unique_id": (i32, [vp]),
+        "dvn_comm_init": (i32, [vp, vp, u32, u32, C.POINTER(vp)]),
+        "dvn_comm_all_gather": (i32, [vp, vp, vp, sz, vp]),
+        "dvn_comm_free": (i32, [vp, vp]),
         "dvn_groth16_prove_multi": (i32, [vp, vp, u32, vp, vp, vp, vp]),
         "dvn_groth16_prove_solved_multi": (i32, [vp, vp, u32, vp, vp, vp, vp, sz, vp, vp, vp]),
         "dvn_bw6761_groth16_prove_solved_multi": (i32, [vp, vp, u32, vp, vp, vp, vp, sz, vp, vp, vp]),
@@ -222,7 +227,7 @@ EXPORTED_SYMBOLS = [
     "dvn_bls12381_points_upload_g1", "dvn_bls12381_points_upload_g2", "dvn_bls12381_points_synthetic_g1", "dvn_bls12381_points_download",
     "dvn_bls12381_scalars_synthetic", "dvn_bls12381_msm_g1", "dvn_bls12381_msm_g2", "dvn_bls12381_ntt_domain", "dvn_bls12381_ntt", "dvn_bls12381_groth16_compute_h",
     "dvn_bls12381_r1cs_synthetic", "dvn_bls12381_groth16_setup", "dvn_bls12381_groth16_prove", "dvn_r1cs_curve",
-    "dvn_r1cs_synthetic_committed", "dvn_groth16_prove_committed", "dvn_groth16_prove_committed_shard", "dvn_groth16_prove_committed_multi", "dvn_groth16_proof_words", "dvn_keccak256", "dvn_groth16_vk_export", "dvn_groth16_pk_import", "dvn_groth16_prove_solved", "dvn_groth16_pk_export_arrays",
+    "dvn_r1cs_synthetic_committed", "dvn_groth16_prove_committed", "dvn_groth16_prove_committed_shard", "dvn_groth16_prove_committed_multi", "dvn_groth16_proof_words", "dvn_keccak256", "dvn_groth16_vk_export", "dvn_groth16_pk_import", "dvn_groth16_prove_solved", "dvn_groth16_prove_solved_shard", "dvn_groth16_pk_export_arrays",
     "dvn_bls12377_groth16_pk_import", "dvn_bls12377_groth16_prove_solved", "dvn_bls12377_groth16_pk_export_arrays", "dvn_bls12381_groth16_pk_import", "dvn_bls12381_groth16_prove_solved", "dvn_bls12381_groth16_pk_export_arrays", "dvn_bw6761_groth16_pk_import", "dvn_bw6761_groth16_prove_solved", "dvn_bw6761_groth16_pk_export_arrays",
     "dvn_kzg_setup_load", "dvn_kzg_setup_free", "dvn_kzg_blob_to_commitment", "dvn_kzg_compute_proof", "dvn_kzg_compute_cell_proofs",
     "dvn_kzg_evaluate_barycentric", "dvn_kzg_compute_blob_proof", "dvn_sha256",
@@ -233,6 +238,7 @@ EXPORTED_SYMBOLS = [
     "dvn_prover_last_backend", "dvn_prover_prove", "dvn_prover_gpu_prover", "dvn_prover_cpu_prover", "dvn_prover_setup",
     "dvn_ctx_device_count", "dvn_ctx_device", "dvn_ctx_device_ordinal", "dvn_error_string",
     "dvn_msm_g1_share_submit", "dvn_msm_g1_share_collect", "dvn_msm_g1_sum", "dvn_msm_g1_multi",
+    "dvn_comm_unique_id", "dvn_comm_init", "dvn_comm_all_gather", "dvn_comm_free",
     "dvn_groth16_prove_multi", "dvn_groth16_prove_solved_multi", "dvn_bw6761_groth16_prove_solved_multi", "dvn_groth16_last_stats_json",
     "dvn_bls12377_pedersen_commit", "dvn_bls12381_pedersen_commit", "dvn_bw6761_pedersen_commit",
     "dvn_gnark_pk_scan", "dvn_groth16_pk_load_bytes", "dvn_groth16_pk_load_file", "dvn_groth16_pk_commitment_bases", "dvn_groth16_pk_evict",
@@ -719,6 +725,39 @@ def msm_g1_multi(ctx: "Context", sets, scalars: np.ndarray, off: int = 0) -> np.
     return out
 
 
+class Comm:
+    """RCCL communicator of the one-process-per-GPU deployment (dvn_comm_*): all-gather of fixed-size uint64 rows, host in / out.
+    `Comm.unique_id()` on rank 0, its 128 bytes to every rank, then `Comm(ctx, id, rank, world)` on all of them (collective)."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        L = load_library()
+        buf = np.zeros(128, dtype=np.uint8)
+        rc = L.dvn_comm_unique_id(C.c_void_p(buf.ctypes.data))
+        if rc != 0:
+            raise DvnError(rc, (L.dvn_last_error(None) or b"").decode())
+        return buf.tobytes()
+
+    def __init__(self, ctx: "Context", uid: bytes, rank: int, world: int):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        buf = np.frombuffer(bytes(uid), dtype=np.uint8).copy()
+        assert buf.size == 128
+        h = C.c_void_p()
+        ctx._chk(ctx.L.dvn_comm_init(ctx.h, C.c_void_p(buf.ctypes.data), rank, world, C.byref(h)))
+        self.h = h
+
+    def all_gather(self, local: np.ndarray) -> np.ndarray:
+        local = np.ascontiguousarray(local, dtype=np.uint64).reshape(-1)
+        out = np.zeros((self.world, local.size), dtype=np.uint64)
+        self.ctx._chk(self.ctx.L.dvn_comm_all_gather(self.ctx.h, self.h, _host(local), local.size, _host(out)))
+        return out
+
+    def free(self):
+        if self.h:
+            self.ctx._chk(self.ctx.L.dvn_comm_free(self.ctx.h, self.h))
+            self.h = None
+
+
 def prove_committed_multi(ctx: "Context", keys, witness: np.ndarray, r_mont, s_mont) -> dict:
     """One committed (statetransition-shaped) BN254 proof over all devices of a multi-device context."""
     arr = (C.c_void_p * len(keys))(*[k.h for k in keys])
@@ -825,6 +864,20 @@ class ImportedKey:
         self.ctx._chk(getattr(self.ctx.L, self._prefix + "groth16_prove_solved")(self.ctx.h, self.h, _host(w), _host(a), _host(b), _host(c), a.shape[0],
                                                                                  _host(r_mont), _host(s_mont), _host(out)))
         return {"Ar": out[0:a1].copy(), "Bs": out[a1:a1 + a2].copy(), "Krs": out[a1 + a2:2 * a1 + a2].copy()}
+
+    def prove_solved_shard(self, w: np.ndarray, a: np.ndarray, b: np.ndarray, c: np.ndarray, rank: int, world: int) -> np.ndarray:
+        """BN254: rank's share of prove_solved as 72 words of partial results (combine with prove_solved_combine)."""
+        w, a, b, c = (np.ascontiguousarray(x, dtype=np.uint64) for x in (w, a, b, c))
+        out = np.zeros(72, dtype=np.uint64)
+        self.ctx._chk(self.ctx.L.dvn_groth16_prove_solved_shard(self.ctx.h, self.h, _host(w), _host(a), _host(b), _host(c), a.shape[0], rank, world, _host(out)))
+        return out
+
+    def prove_solved_combine(self, partials: np.ndarray, r_mont, s_mont) -> dict:
+        partials = np.ascontiguousarray(partials, dtype=np.uint64).reshape(-1, 72)
+        r_mont = np.ascontiguousarray(r_mont, dtype=np.uint64); s_mont = np.ascontiguousarray(s_mont, dtype=np.uint64)
+        out = np.zeros(32, dtype=np.uint64)
+        self.ctx._chk(self.ctx.L.dvn_groth16_prove_combine(self.h, _host(partials), partials.shape[0], _host(r_mont), _host(s_mont), _host(out)))
+        return {"Ar": out[0:8].copy(), "Bs": out[8:24].copy(), "Krs": out[24:32].copy()}
 
     def free(self):
         if self.h:

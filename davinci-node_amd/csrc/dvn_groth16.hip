@@ -22,6 +22,10 @@ extern "C" int32_t dvn_groth16_prove_shard(dvn_ctx* ctx, dvn_groth16_pk* pk, con
                                            uint32_t rank, uint32_t world, uint64_t partial_out[72]) try {
     return groth16_prove_shard<SuiteBn254>(ctx, pk, witness, flags, rank, world, partial_out);
 } DVN_CATCH
+extern "C" int32_t dvn_groth16_prove_solved_shard(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b, const uint64_t* c,
+                                                  size_t len, uint32_t rank, uint32_t world, uint64_t partial_out[72]) try {
+    return groth16_prove_solved_shard<SuiteBn254>(ctx, pk, w, a, b, c, len, rank, world, partial_out);
+} DVN_CATCH
 extern "C" int32_t dvn_groth16_prove_combine(const dvn_groth16_pk* pk, const uint64_t* partials, uint32_t world,
                                              const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[32]) try {
     return groth16_prove_combine<SuiteBn254>(pk, partials, world, r_mont, s_mont, proof_out);

@@ -850,6 +850,26 @@ template <class SU> static int32_t groth16_prove_shard(dvn_ctx* ctx, dvn_groth16
     H1::write_jac(R.mZ, partial_out + 3 * J1); H2::write_jac(R.mB2, partial_out + 4 * J1);
     return DVN_OK;
 }
+// the same share from the solver's output (gnark's own keys, imported or loaded: they have no constraint system here)
+template <class SU> static int32_t groth16_prove_solved_shard(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b,
+                                                              const uint64_t* c, size_t len, uint32_t rank, uint32_t world, uint64_t* partial_out) {
+    typedef typename SU::H1 H1;
+    typedef typename SU::H2 H2;
+    TRY(enter(ctx));
+    if (!pk || !w || !a || !b || !c || !partial_out) return fail(DVN_ERR_INVALID_ARG, "NULL argument");
+    if (pk->suite != SU::SUITE) return fail(DVN_ERR_INVALID_ARG, "proving key belongs to another curve");
+    if (world < 1 || world > 64 || rank >= world) return fail(DVN_ERR_INVALID_ARG, "rank %u outside world %u", rank, world);
+    if (len > pk->n) return fail(DVN_ERR_INVALID_ARG, "len = %zu exceeds the domain size %zu", len, pk->n);
+    if (pk->n_committed && !pk->imported) return fail(DVN_ERR_INVALID_ARG, "the key carries a BSB22 commitment: use dvn_groth16_prove_committed_shard");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const uint64_t* src[3] = {a, b, c};
+    MsmResults<SU> R;
+    TRY(groth16_device<SU>(ctx, pk, w, 0u, rank, world, &R, src, len));
+    constexpr size_t J1 = PartialLayout<SU>::J1;
+    H1::write_jac(R.mA, partial_out); H1::write_jac(R.mB, partial_out + J1); H1::write_jac(R.mK, partial_out + 2 * J1);
+    H1::write_jac(R.mZ, partial_out + 3 * J1); H2::write_jac(R.mB2, partial_out + 4 * J1);
+    return DVN_OK;
+}
 // host only: partials = world x PartialLayout::WORDS as gathered from the ranks
 template <class SU> static int32_t groth16_prove_combine(const dvn_groth16_pk* pk, const uint64_t* partials, uint32_t world,
                                                          const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out) {

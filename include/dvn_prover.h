@@ -408,6 +408,11 @@ int32_t dvn_groth16_pk_export_arrays(dvn_ctx* ctx, const dvn_groth16_pk* pk, int
 int32_t dvn_groth16_prove_solved_multi(dvn_ctx* ctx, dvn_groth16_pk* const* keys, uint32_t nkeys, const uint64_t* w, const uint64_t* a,
                                        const uint64_t* b, const uint64_t* c, size_t len, const uint64_t r_mont[4], const uint64_t s_mont[4],
                                        uint64_t proof_out[32]);
+/* ... and rank `rank` of `world`'s share of it for one-process-per-GPU deployments: partial_out as dvn_groth16_prove_shard's
+ * (72 words); the ranks exchange them (dvn_comm_all_gather) and dvn_groth16_prove_combine assembles the proof.  Host w, a, b, c.
+ * No counterpart in the reference (prover/prover_gpu.go:33 proves on one GPU). */
+int32_t dvn_groth16_prove_solved_shard(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b,
+                                       const uint64_t* c, size_t len, uint32_t rank, uint32_t world, uint64_t partial_out[72]);
 int32_t dvn_bw6761_groth16_prove_solved_multi(dvn_ctx* ctx, dvn_groth16_pk* const* keys, uint32_t nkeys, const uint64_t* w, const uint64_t* a,
                                               const uint64_t* b, const uint64_t* c, size_t len, const uint64_t* r_mont, const uint64_t* s_mont,
                                               uint64_t* proof_out);
@@ -532,6 +537,22 @@ int32_t dvn_kzg_compute_blob_proof(dvn_ctx* ctx, const dvn_kzg_setup* setup, con
 int32_t dvn_sha256(const uint8_t* data, size_t len, uint8_t out[32]);        /* host only */
 int32_t dvn_kzg_compute_cell_proofs(dvn_ctx* ctx, const dvn_kzg_setup* setup, const uint8_t* blob, uint8_t* proofs /* 128 x 48 */);
 int32_t dvn_kzg_evaluate_barycentric(dvn_ctx* ctx, const dvn_kzg_setup* setup, const uint8_t* blob, const uint8_t z[32], uint8_t y[32]);
+
+/* ---- the exchange step for hosts that run one PROCESS per GPU (csrc/dvn_comm.hip) -----------------------------------
+ * No counterpart in the reference, whose ICICLE backend drives one GPU (prover/prover_gpu.go:24-61); the serialisation point
+ * a sharded proof shortens is sequencer/statetransition.go:80.  An RCCL communicator over xGMI: rank 0 makes an id
+ * (dvn_comm_unique_id) and hands the 128 bytes to the other processes by any means; every rank calls dvn_comm_init with it
+ * (a collective: it returns when all `world` ranks have called); dvn_comm_all_gather then gives every rank the `words` uint64
+ * of every rank (rank r's at all[r * words ...]) -- the 12-word partial sums of dvn_msm_g1_share_collect, added with
+ * dvn_msm_g1_sum, or the 72-word partial results of dvn_groth16_prove_shard, assembled with dvn_groth16_prove_combine.
+ * RCCL has no elliptic-curve reduction operator, so the "all-reduce" of partial sums is this all-gather plus the local sum.
+ * Host buffers in and out; words <= DVN_COMM_MAX_WORDS.  librccl is opened at the first call of this group, not linked. */
+typedef struct dvn_comm dvn_comm;
+#define DVN_COMM_MAX_WORDS 4096
+int32_t dvn_comm_unique_id(uint8_t id[128]);
+int32_t dvn_comm_init(dvn_ctx* ctx, const uint8_t id[128], uint32_t rank, uint32_t world, dvn_comm** out);
+int32_t dvn_comm_all_gather(dvn_ctx* ctx, dvn_comm* comm, const uint64_t* local, size_t words, uint64_t* all /* world x words */);
+int32_t dvn_comm_free(dvn_ctx* ctx, dvn_comm* comm);
 
 /* ---- the entry point that allocates nothing ------------------------------------------------------------------------
  * No counterpart in the reference: this one is for callers that cannot call hipMalloc -- tight serving loops, harnesses

@@ -241,6 +241,14 @@ def test_imported_key_proves_from_solver_output(ctx, pkg, opy, orc, n_constraint
     _, closed = orc.groth16_synthetic_expected(7, n_constraints, 9, 3, r, s)
     for k in ("Ar", "Bs", "Krs"):
         assert (got[k] == want[k]).all() and (got[k] == closed[k]).all(), k
+    # the same proof from the shares of worlds 1, 2, 5 (one process per GPU: dvn_groth16_prove_solved_shard + exchange + combine)
+    for world in (1, 2, 5):
+        parts = np.stack([ik.prove_solved_shard(cs.witness(), a, b, c, rk, world) for rk in range(world)])
+        shared = ik.prove_solved_combine(parts, r, s)
+        for k in ("Ar", "Bs", "Krs"):
+            assert (shared[k] == want[k]).all(), (world, k)
+    with pytest.raises(pkg.DvnError):
+        ik.prove_solved_shard(cs.witness(), a, b, c, 2, 2)
     # an imported key has no constraint system: the R1CS entry points refuse it; oversized solver output is rejected
     out = np.zeros(32, dtype=np.uint64)
     w = cs.witness()

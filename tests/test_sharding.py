@@ -211,6 +211,64 @@ def test_bench_distributed_path_on_rccl_with_one_rank():
     assert sh["ranks"] == 1 and sh["all_ranks_same_proof"] is True and sh["equals_single_gpu_proof"] is True
 
 
+_COMM_ONE_RANK = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+import __graft_entry__ as g
+pkg = g.load_package()
+from oracle import cpu as orc
+ctx = pkg.Context(0)
+uid = pkg.Comm.unique_id()
+assert len(uid) == 128 and any(uid)
+comm = pkg.Comm(ctx, uid, 0, 1)
+n = 1 << 16
+pts = ctx.synthetic_g1(5, n); d = ctx.synthetic_scalars(3, 0, n)
+want = orc.g1_jac_to_affine(ctx.msm_g1(pts, d, n=n))
+part = ctx.msm_g1_share_collect(ctx.msm_g1_share_submit(pts, d, n, 0, 1))
+rows = comm.all_gather(part)                                   # the exchange of a shared MSM: 12 words per rank
+assert rows.shape == (1, 12) and (rows[0] == part).all()
+assert (orc.g1_jac_to_affine(ctx.msm_g1_sum(rows)) == want).all()
+cs = pkg.R1CS(7, 3000, 9); key = pkg.Groth16Key(ctx, cs, 3); dw = ctx.to_device(cs.witness())
+rs = np.zeros((2, 4), dtype=np.uint64); rs[0, 0], rs[1, 0] = 5, 7
+single = key.prove(dw, rs[0], rs[1])
+proof = key.prove_combine(comm.all_gather(key.prove_shard(dw, 0, 1)), rs[0], rs[1])      # ... and of a shared proof: 72 words
+assert all((single[k] == proof[k]).all() for k in single)
+big = np.arange(4096, dtype=np.uint64)
+assert (comm.all_gather(big)[0] == big).all()
+for bad in (np.zeros(4097, dtype=np.uint64), np.zeros(0, dtype=np.uint64)):
+    try:
+        comm.all_gather(bad); raise SystemExit("oversized / empty all-gather was accepted")
+    except pkg.DvnError as e:
+        assert "between 1 and 4096" in str(e)
+try:
+    pkg.Comm(ctx, uid, 3, 2); raise SystemExit("rank outside the world was accepted")
+except pkg.DvnError:
+    pass
+comm.free()
+print("COMM_ONE_RANK_OK", flush=True)
+"""
+
+
+@pytest.mark.gpu
+def test_library_communicator_on_rccl_with_one_rank():
+    """dvn_comm_* (the exchange primitive a one-process-per-GPU Go deployment binds, RCCL opened by the library itself, no torch):
+    id, init, all-gather of an MSM share and of a proof share, limits, free -- with a world of one rank, which is what a
+    one-GPU box can run (RCCL refuses two ranks on one device).  Own process: RCCL keeps threads and state."""
+    import subprocess
+    out = subprocess.run([sys.executable, "-c", _COMM_ONE_RANK.format(root=ROOT)], capture_output=True, text=True, timeout=200, cwd=ROOT)
+    assert out.returncode == 0 and "COMM_ONE_RANK_OK" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+
+
+def test_library_communicator_rejects_bad_arguments_without_a_device():
+    import ctypes as C
+    from __graft_entry__ import load_package
+    L = load_package().load_library()
+    assert L.dvn_comm_unique_id(None) != 0
+    assert L.dvn_comm_free(None, None) == 0                    # freeing nothing is not an error
+    assert L.dvn_comm_init(None, None, 0, 1, None) != 0 and L.dvn_comm_all_gather(None, None, None, 1, None) != 0
+
+
 def test_bench_exit_status_reports_failed_extras():
     """Source-level contract of bench.py's N > 1 tail: both failure paths (watchdog, exception in the extras) leave with a
     non-zero status after printing the line, never 0."""
