@@ -411,4 +411,33 @@ def test_msm_g1_batched_argument_errors(ctx, pkg, orc):
     with pytest.raises(pkg.DvnError):
         ctx.msm_g1_batched(pts, np.zeros((2, 65, 4), dtype=np.uint64))       # len(points) != len(scalars)
     assert ctx.msm_g1_batched(pts, np.zeros((0, 64, 4), dtype=np.uint64)).shape == (0, 12)
-    pts.free()
+    pts.free()@pytest.mark.gpu
+def test_outstanding_tickets_make_synchronous_calls_fail_cleanly(ctx, orc, pkg):
+    """The four lanes are shared by tickets and synchronous calls: with four tickets outstanding an MSM and a proof fail with
+    the documented message (no wait, no partial state, no leaked lane); once the tickets are collected both work again and
+    the collected results are right."""
+    n = 5000
+    ph = orc.g1_synthetic_points(77, n); pts = ctx.upload_g1(ph)
+    sc = orc.scalars(8, 0, n); want = orc.msm_g1(ph, sc)
+    cs = pkg.R1CS(7, 2000, 9); key = pkg.Groth16Key(ctx, cs, 3); w = cs.witness()
+    r = np.array([5, 0, 0, 0], dtype=np.uint64); s = np.array([7, 0, 0, 0], dtype=np.uint64)
+    proof = key.prove(w, r, s)
+    for _ in range(2):
+        tickets = [ctx.msm_g1_submit(pts, sc) for _ in range(4)]
+        with pytest.raises(pkg.DvnError, match="too many MSMs in flight"):
+            ctx.msm_g1_submit(pts, sc)
+        with pytest.raises(pkg.DvnError, match="too many MSMs in flight"):
+            ctx.msm_g1(pts, sc)
+        with pytest.raises(pkg.DvnError, match="too many MSMs in flight"):
+            key.prove(w, r, s)
+        first = ctx.msm_g1_collect(tickets.pop(0))                 # one lane back: a single MSM fits, a proof (several lanes) may not
+        assert (aff1(orc, first) == want).all()
+        assert (aff1(orc, ctx.msm_g1(pts, sc)) == want).all()
+        for t in tickets:
+            assert (aff1(orc, ctx.msm_g1_collect(t)) == want).all()
+        again = key.prove(w, r, s)
+        assert all((again[k] == proof[k]).all() for k in proof)
+    key.free(); cs.free(); pts.free()
+
+
+
