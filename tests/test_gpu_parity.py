@@ -411,7 +411,10 @@ def test_msm_g1_batched_argument_errors(ctx, pkg, orc):
     with pytest.raises(pkg.DvnError):
         ctx.msm_g1_batched(pts, np.zeros((2, 65, 4), dtype=np.uint64))       # len(points) != len(scalars)
     assert ctx.msm_g1_batched(pts, np.zeros((0, 64, 4), dtype=np.uint64)).shape == (0, 12)
-    pts.free()@pytest.mark.gpu
+    pts.free()
+
+
+@pytest.mark.gpu
 def test_outstanding_tickets_make_synchronous_calls_fail_cleanly(ctx, orc, pkg):
     """The four lanes are shared by tickets and synchronous calls: with four tickets outstanding an MSM and a proof fail with
     the documented message (no wait, no partial state, no leaked lane); once the tickets are collected both work again and
@@ -438,6 +441,3 @@ def test_outstanding_tickets_make_synchronous_calls_fail_cleanly(ctx, orc, pkg):
         again = key.prove(w, r, s)
         assert all((again[k] == proof[k]).all() for k in proof)
     key.free(); cs.free(); pts.free()
-
-
-
