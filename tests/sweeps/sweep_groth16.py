@@ -14,8 +14,11 @@ R = o.R
 mont = lambda x: np.array(o.limbs(o.to_mont(x % R, R)), dtype=np.uint64)
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4242)
 t_end = time.time() + budget
+t_note = time.time() + 30                       # a progress line every half minute: a silent run looks hung to the harness
 cases = 0
 while time.time() < t_end:
+    if time.time() > t_note:
+        print(f"{cases} cases so far", flush=True); t_note = time.time() + 30
     nc = int(rng.choice([2, 3, 4, 5, 17, 64, 65, 255, 256, 257, 1000, 1023, 1024, 1025, 3000, 4097, 9000, 20011, 40000]))
     npub = int(rng.integers(1, min(nc, 24)))
     cs_seed, key_seed = int(rng.integers(1, 1 << 20)), int(rng.integers(1, 1 << 20))

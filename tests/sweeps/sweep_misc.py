@@ -15,8 +15,11 @@ R = o.R
 mont = lambda x: np.array(o.limbs(o.to_mont(x % R, R)), dtype=np.uint64)
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
 t_end = time.time() + budget
+t_note = time.time() + 30                       # a progress line every half minute: a silent run looks hung to the harness
 cases = refused = 0
 while time.time() < t_end:
+    if time.time() > t_note:
+        print(f"{cases} cases so far", flush=True); t_note = time.time() + 30
     # ---- the allocation-free MSM
     n = int(rng.choice([1, 2, 100, 1023, 1024, 1025, 4000, 8192, 8193, 30000, 32768, 50000, 65535, 65536]))
     seed = int(rng.integers(1, 1 << 30)); kind = int(rng.integers(0, 2))

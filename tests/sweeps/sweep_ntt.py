@@ -12,8 +12,11 @@ ctx = pkg.Context(0)
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 99)
 doms = {}
 t_end = time.time() + budget
+t_note = time.time() + 30                       # a progress line every half minute: a silent run looks hung to the harness
 cases = 0
 while time.time() < t_end:
+    if time.time() > t_note:
+        print(f"{cases} cases so far", flush=True); t_note = time.time() + 30
     log_n = int(rng.integers(1, 18)); n = 1 << log_n
     dom = doms.get(log_n) or doms.setdefault(log_n, ctx.domain(log_n))
     seed = int(rng.integers(1, 1 << 30))

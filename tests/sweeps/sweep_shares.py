@@ -12,8 +12,11 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 ctx = pkg.Context(0)
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 777)
 t_end = time.time() + budget
+t_note = time.time() + 30                       # a progress line every half minute: a silent run looks hung to the harness
 cases = 0
 while time.time() < t_end:
+    if time.time() > t_note:
+        print(f"{cases} cases so far", flush=True); t_note = time.time() + 30
     n = int(rng.choice([1, 2, 7, 100, 1000, 1023, 1024, 1025, 5000, 8191, 8193, 20000, 40001, 70000]))
     seed = int(rng.integers(1, 1 << 30)); kind = int(rng.integers(0, 2))
     ph = orc.g1_synthetic_points(seed, n); pts = ctx.upload_g1(ph)
