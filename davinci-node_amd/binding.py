@@ -128,6 +128,10 @@ def load_library():
         "dvn_groth16_pk_import": (i32, [vp, vp, C.POINTER(vp)]),
         "dvn_groth16_prove_solved": (i32, [vp, vp, vp, vp, vp, vp, sz, vp, vp, vp]),
         "dvn_groth16_prove_solved_shard": (i32, [vp, vp, vp, vp, vp, vp, sz, u32, u32, vp]),
+        "dvn_bls12377_groth16_prove_solved_shard": (i32, [vp, vp, vp, vp, vp, vp, sz, u32, u32, vp]),
+        "dvn_bw6761_groth16_prove_solved_shard": (i32, [vp, vp, vp, vp, vp, vp, sz, u32, u32, vp]),
+        "dvn_bls12377_groth16_prove_combine": (i32, [vp, vp, u32, vp, vp, vp]),
+        "dvn_bw6761_groth16_prove_combine": (i32, [vp, vp, u32, vp, vp, vp]),
         "dvn_groth16_pk_export_arrays": (i32, [vp, vp, C.c_int, vp, sz, C.POINTER(sz)]),
         "dvn_bls12377_groth16_pk_import": (i32, [vp, vp, C.POINTER(vp)]),
         "dvn_bls12377_groth16_prove_solved": (i32, [vp, vp, vp, vp, vp, vp, sz, vp, vp, vp]),
@@ -227,7 +231,8 @@ EXPORTED_SYMBOLS = [
     "dvn_bls12381_points_upload_g1", "dvn_bls12381_points_upload_g2", "dvn_bls12381_points_synthetic_g1", "dvn_bls12381_points_download",
     "dvn_bls12381_scalars_synthetic", "dvn_bls12381_msm_g1", "dvn_bls12381_msm_g2", "dvn_bls12381_ntt_domain", "dvn_bls12381_ntt", "dvn_bls12381_groth16_compute_h",
     "dvn_bls12381_r1cs_synthetic", "dvn_bls12381_groth16_setup", "dvn_bls12381_groth16_prove", "dvn_r1cs_curve",
-    "dvn_r1cs_synthetic_committed", "dvn_groth16_prove_committed", "dvn_groth16_prove_committed_shard", "dvn_groth16_prove_committed_multi", "dvn_groth16_proof_words", "dvn_keccak256", "dvn_groth16_vk_export", "dvn_groth16_pk_import", "dvn_groth16_prove_solved", "dvn_groth16_prove_solved_shard", "dvn_groth16_pk_export_arrays",
+    "dvn_r1cs_synthetic_committed", "dvn_groth16_prove_committed", "dvn_groth16_prove_committed_shard", "dvn_groth16_prove_committed_multi", "dvn_groth16_proof_words", "dvn_keccak256", "dvn_groth16_vk_export", "dvn_groth16_pk_import", "dvn_groth16_prove_solved", "dvn_groth16_prove_solved_shard", "dvn_bls12377_groth16_prove_solved_shard", "dvn_bw6761_groth16_prove_solved_shard",
+    "dvn_bls12377_groth16_prove_combine", "dvn_bw6761_groth16_prove_combine", "dvn_groth16_pk_export_arrays",
     "dvn_bls12377_groth16_pk_import", "dvn_bls12377_groth16_prove_solved", "dvn_bls12377_groth16_pk_export_arrays", "dvn_bls12381_groth16_pk_import", "dvn_bls12381_groth16_prove_solved", "dvn_bls12381_groth16_pk_export_arrays", "dvn_bw6761_groth16_pk_import", "dvn_bw6761_groth16_prove_solved", "dvn_bw6761_groth16_pk_export_arrays",
     "dvn_kzg_setup_load", "dvn_kzg_setup_free", "dvn_kzg_blob_to_commitment", "dvn_kzg_compute_proof", "dvn_kzg_compute_cell_proofs",
     "dvn_kzg_evaluate_barycentric", "dvn_kzg_compute_blob_proof", "dvn_sha256",
@@ -866,18 +871,23 @@ class ImportedKey:
         return {"Ar": out[0:a1].copy(), "Bs": out[a1:a1 + a2].copy(), "Krs": out[a1 + a2:2 * a1 + a2].copy()}
 
     def prove_solved_shard(self, w: np.ndarray, a: np.ndarray, b: np.ndarray, c: np.ndarray, rank: int, world: int) -> np.ndarray:
-        """BN254: rank's share of prove_solved as 72 words of partial results (combine with prove_solved_combine)."""
+        """rank's share of prove_solved: the partial results of the five MSMs (4 G1 + 1 G2 Jacobian images; combine with prove_solved_combine)."""
         w, a, b, c = (np.ascontiguousarray(x, dtype=np.uint64) for x in (w, a, b, c))
-        out = np.zeros(72, dtype=np.uint64)
-        self.ctx._chk(self.ctx.L.dvn_groth16_prove_solved_shard(self.ctx.h, self.h, _host(w), _host(a), _host(b), _host(c), a.shape[0], rank, world, _host(out)))
+        out = np.zeros(self.partial_words, dtype=np.uint64)
+        self.ctx._chk(getattr(self.ctx.L, self._prefix + "groth16_prove_solved_shard")(self.ctx.h, self.h, _host(w), _host(a), _host(b), _host(c), a.shape[0], rank, world, _host(out)))
         return out
 
+    @property
+    def partial_words(self) -> int:
+        return 6 * self._a1 + 3 * self._a2 // 2              # four G1 images of 3 coordinates, one G2 image
+
     def prove_solved_combine(self, partials: np.ndarray, r_mont, s_mont) -> dict:
-        partials = np.ascontiguousarray(partials, dtype=np.uint64).reshape(-1, 72)
+        partials = np.ascontiguousarray(partials, dtype=np.uint64).reshape(-1, self.partial_words)
         r_mont = np.ascontiguousarray(r_mont, dtype=np.uint64); s_mont = np.ascontiguousarray(s_mont, dtype=np.uint64)
-        out = np.zeros(32, dtype=np.uint64)
-        self.ctx._chk(self.ctx.L.dvn_groth16_prove_combine(self.h, _host(partials), partials.shape[0], _host(r_mont), _host(s_mont), _host(out)))
-        return {"Ar": out[0:8].copy(), "Bs": out[8:24].copy(), "Krs": out[24:32].copy()}
+        a1, a2 = self._a1, self._a2
+        out = np.zeros(2 * a1 + a2, dtype=np.uint64)
+        self.ctx._chk(getattr(self.ctx.L, self._prefix + "groth16_prove_combine")(self.h, _host(partials), partials.shape[0], _host(r_mont), _host(s_mont), _host(out)))
+        return {"Ar": out[0:a1].copy(), "Bs": out[a1:a1 + a2].copy(), "Krs": out[a1 + a2:2 * a1 + a2].copy()}
 
     def free(self):
         if self.h:

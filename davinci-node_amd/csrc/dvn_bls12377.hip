@@ -88,6 +88,15 @@ extern "C" int32_t dvn_bls12377_groth16_prove_solved(dvn_ctx* ctx, dvn_groth16_p
                                               const uint64_t* r_mont, const uint64_t* s_mont, uint64_t* proof_out) try {
     return groth16_prove_solved<SuiteBls12377>(ctx, pk, w, a, b, c, len, r_mont, s_mont, proof_out);
 } DVN_CATCH
+// rank's share of dvn_bls12377_groth16_prove_solved and the assembly of the gathered shares (see dvn_groth16_prove_solved_shard / _combine)
+extern "C" int32_t dvn_bls12377_groth16_prove_solved_shard(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b, const uint64_t* c, size_t len,
+                                                    uint32_t rank, uint32_t world, uint64_t* partial_out) try {
+    return groth16_prove_solved_shard<SuiteBls12377>(ctx, pk, w, a, b, c, len, rank, world, partial_out);
+} DVN_CATCH
+extern "C" int32_t dvn_bls12377_groth16_prove_combine(const dvn_groth16_pk* pk, const uint64_t* partials, uint32_t world, const uint64_t* r_mont, const uint64_t* s_mont,
+                                               uint64_t* proof_out) try {
+    return groth16_prove_combine<SuiteBls12377>(pk, partials, world, r_mont, s_mont, proof_out);
+} DVN_CATCH
 extern "C" int32_t dvn_bls12377_groth16_pk_export_arrays(dvn_ctx* ctx, const dvn_groth16_pk* pk, int which, uint64_t* out, size_t cap_words, size_t* n_words) try {
     return groth16_pk_export_arrays<SuiteBls12377>(ctx, pk, which, out, cap_words, n_words);
 } DVN_CATCH

@@ -413,6 +413,16 @@ int32_t dvn_groth16_prove_solved_multi(dvn_ctx* ctx, dvn_groth16_pk* const* keys
  * No counterpart in the reference (prover/prover_gpu.go:33 proves on one GPU). */
 int32_t dvn_groth16_prove_solved_shard(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b,
                                        const uint64_t* c, size_t len, uint32_t rank, uint32_t world, uint64_t partial_out[72]);
+/* the same pair on the voteverifier and aggregator curves: partial results of 108 (BLS12-377) / 180 (BW6-761) uint64 per rank,
+ * proofs of 48 / 72 words as dvn_<curve>_groth16_prove_solved writes them; r_mont / s_mont of 4 / 6 words */
+int32_t dvn_bls12377_groth16_prove_solved_shard(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b,
+                                                const uint64_t* c, size_t len, uint32_t rank, uint32_t world, uint64_t partial_out[108]);
+int32_t dvn_bls12377_groth16_prove_combine(const dvn_groth16_pk* pk, const uint64_t* partials /* world x 108 */, uint32_t world,
+                                           const uint64_t r_mont[4], const uint64_t s_mont[4], uint64_t proof_out[48]);
+int32_t dvn_bw6761_groth16_prove_solved_shard(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b,
+                                              const uint64_t* c, size_t len, uint32_t rank, uint32_t world, uint64_t partial_out[180]);
+int32_t dvn_bw6761_groth16_prove_combine(const dvn_groth16_pk* pk, const uint64_t* partials /* world x 180 */, uint32_t world,
+                                         const uint64_t r_mont[6], const uint64_t s_mont[6], uint64_t proof_out[72]);
 int32_t dvn_bw6761_groth16_prove_solved_multi(dvn_ctx* ctx, dvn_groth16_pk* const* keys, uint32_t nkeys, const uint64_t* w, const uint64_t* a,
                                               const uint64_t* b, const uint64_t* c, size_t len, const uint64_t* r_mont, const uint64_t* s_mont,
                                               uint64_t* proof_out);

@@ -125,6 +125,27 @@ def test_imported_key_on_other_curves(ctx, pkg, S):
         assert (got[k] == want[k]).all(), k
     assert list(got["Ar"]) == S.g1_to_limbs(closed["Ar"]) and list(got["Krs"]) == S.g1_to_limbs(closed["Krs"])
     ik.free(); key.free(); cs.free()
+    if S.cname == "bls12381":
+        return
+    # one process per GPU on the voteverifier / aggregator curves: the shares of worlds 1, 2, 5 (dvn_<curve>_groth16_prove_solved_shard,
+    # key sets large enough to be shared by entry count) assemble to the same proof (dvn_<curve>_groth16_prove_combine)
+    n_constraints = 5000
+    cs = pkg.R1CS(4, n_constraints, n_public, curve=S.cname)
+    ocs = cp.SyntheticR1CSOn(S, n_constraints, n_public, 4)
+    key = pkg.Groth16Key(ctx, cs, 9)
+    assert min(key.sizes["A"], key.sizes["B"]) >= 1 << 10
+    ik = pkg.ImportedKey(ctx, key.log_n, cs.n_wires, key.export_arrays(cs.n_wires, cs.n_public), curve=S.cname)
+    w = cs.witness(); a, b, c = ev(ocs.A), ev(ocs.B), ev(ocs.C)
+    whole = ik.prove_solved(w, a, b, c, rl, sl)
+    for world in (1, 2, 5):
+        parts = np.stack([ik.prove_solved_shard(w, a, b, c, rk, world) for rk in range(world)])
+        assert parts.shape[1] == {"bls12377": 108, "bw6761": 180}[S.cname]
+        shared = ik.prove_solved_combine(parts, rl, sl)
+        for k in ("Ar", "Bs", "Krs"):
+            assert (shared[k] == whole[k]).all(), (world, k)
+    with pytest.raises(pkg.DvnError):
+        ik.prove_solved_shard(w, a, b, c, 5, 5)
+    ik.free(); key.free(); cs.free()
 
 
 @pytest.mark.gpu
