@@ -5,6 +5,8 @@
 #include "dvn_internal.h"
 #include <stdexcept>
 #include <system_error>
+#include <atomic>
+#include <thread>
 
 thread_local std::string tl_error;
 // ---- profiler markers (DVN_ROCTX=1): roctxRangePushA / roctxRangePop of whichever roctx library is installed -------------
@@ -130,6 +132,72 @@ extern "C" const char* dvn_error_string(int32_t code) {
         default: return "unknown error code";
     }
 }
+// ---- staged host-to-device copies (declared in dvn_internal.h) ----------------------------------------------------------
+static bool h2d_ready(dvn_ctx* ctx) {
+    if (ctx->h2d_state != 0) return ctx->h2d_state > 0;
+    ctx->h2d_state = -1;
+    const char* v = getenv("DVN_H2D_STAGED");
+    if (v && v[0] == '0') return false;
+    bool ok = hipStreamCreateWithFlags(&ctx->h2d_stream, hipStreamNonBlocking) == hipSuccess
+              && hipEventCreateWithFlags(&ctx->h2d_ev, hipEventDisableTiming) == hipSuccess;
+    for (int b = 0; ok && b < DVN_H2D_BUFS; ++b)
+        ok = hipHostMalloc(&ctx->h2d_pinned[b], DVN_H2D_CHUNK, hipHostMallocDefault) == hipSuccess
+             && hipEventCreateWithFlags(&ctx->h2d_done[b], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); return false; }             // what was created is released with the context
+    ctx->h2d_state = 1;
+    return true;
+}
+static void h2d_release(dvn_ctx* ctx) {
+    if (ctx->h2d_stream) (void)hipStreamSynchronize(ctx->h2d_stream);
+    for (int b = 0; b < DVN_H2D_BUFS; ++b) {
+        if (ctx->h2d_pinned[b]) (void)hipHostFree(ctx->h2d_pinned[b]);
+        if (ctx->h2d_done[b]) (void)hipEventDestroy(ctx->h2d_done[b]);
+    }
+    if (ctx->h2d_ev) (void)hipEventDestroy(ctx->h2d_ev);
+    if (ctx->h2d_stream) (void)hipStreamDestroy(ctx->h2d_stream);
+}
+int32_t dvn_h2d(dvn_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t consumer) {
+    if (bytes == 0) return DVN_OK;
+    if (bytes < DVN_H2D_MIN || !h2d_ready(ctx)) {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, consumer));      // pageable source: returns once it is staged
+        return DVN_OK;
+    }
+    static_assert(DVN_H2D_BUFS % DVN_H2D_THREADS == 0, "a ring buffer must always be refilled by the thread that filled it before");
+    // the copy stream starts behind what the consumer has queued so far (earlier readers and writers of dst)
+    HIP_TRY(hipEventRecord(ctx->h2d_ev, consumer));
+    HIP_TRY(hipStreamWaitEvent(ctx->h2d_stream, ctx->h2d_ev, 0));
+    const size_t nchunk = (bytes + DVN_H2D_CHUNK - 1) / DVN_H2D_CHUNK;
+    std::atomic<int> err{(int)hipSuccess};
+    auto work = [&](int tid) {
+        hipError_t e = hipSetDevice(ctx->device);
+        for (size_t i = (size_t)tid; e == hipSuccess && i < nchunk && err.load() == (int)hipSuccess; i += DVN_H2D_THREADS) {
+            const int b = (int)(i % DVN_H2D_BUFS);
+            const size_t off = i * DVN_H2D_CHUNK, len = std::min(DVN_H2D_CHUNK, bytes - off);
+            e = hipEventSynchronize(ctx->h2d_done[b]);              // the chunk this buffer carried before has left it (also a previous call's)
+            if (e != hipSuccess) break;
+            memcpy(ctx->h2d_pinned[b], (const char*)src + off, len);
+            e = hipMemcpyAsync((char*)dst + off, ctx->h2d_pinned[b], len, hipMemcpyHostToDevice, ctx->h2d_stream);
+            if (e == hipSuccess) e = hipEventRecord(ctx->h2d_done[b], ctx->h2d_stream);
+        }
+        if (e != hipSuccess) err.store((int)e);
+    };
+    std::thread th[DVN_H2D_THREADS - 1];
+    int started = 0;
+    try {
+        for (; started < DVN_H2D_THREADS - 1; ++started) th[started] = std::thread(work, started + 1);
+    } catch (...) { /* no more threads: this one takes their shares below */ }
+    work(0);
+    for (int t = started; t < DVN_H2D_THREADS - 1; ++t) work(t + 1);
+    for (int t = 0; t < started; ++t) th[t].join();
+    if (err.load() != (int)hipSuccess) {
+        (void)hipGetLastError();
+        return fail(DVN_ERR_DEVICE, "staged host-to-device copy failed: %s", hipGetErrorString((hipError_t)err.load()));
+    }
+    HIP_TRY(hipEventRecord(ctx->h2d_ev, ctx->h2d_stream));
+    HIP_TRY(hipStreamWaitEvent(consumer, ctx->h2d_ev, 0));
+    return DVN_OK;
+}
+
 int32_t dvn_internal_key_cache_clear(dvn_ctx* ctx);      // dvn_artifacts.hip
 extern "C" void dvn_shutdown(dvn_ctx* ctx) {
     if (!ctx) return;
@@ -138,6 +206,7 @@ extern "C" void dvn_shutdown(dvn_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)dvn_internal_key_cache_clear(ctx);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    h2d_release(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
     for (int l = 0; l < DVN_LANES; ++l) {
         MsmLane& L = ctx->lane[l];

@@ -233,7 +233,8 @@ static int32_t committed_prepare(dvn_ctx* ctx, dvn_groth16_pk* pk, const uint64_
     typedef dvn_host::HG1 H1;
     constexpr u32 EW = 8;
     hipStream_t st = ctx->stream;
-    HIP_TRY(hipMemcpyAsync(pk->d_w, witness, pk->m * EW * 4, (flags & 1) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    if (flags & 1) HIP_TRY(hipMemcpyAsync(pk->d_w, witness, pk->m * EW * 4, hipMemcpyDeviceToDevice, st));
+    else TRY(dvn_h2d(ctx, pk->d_w, witness, pk->m * EW * 4, st));
     // the public wires the challenge hashes (they are the first n_public wires): from the caller's host copy, or in ONE copy back
     // that runs under the two MSMs below
     std::vector<u32> pubw((size_t)pk->n_public * EW);

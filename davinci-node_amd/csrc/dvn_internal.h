@@ -39,6 +39,9 @@ struct MsmLane {
 };
 constexpr int DVN_LANES = 4;
 constexpr size_t DVN_HSUMS_WORDS = 64 * 128;    // up to 64 windows of the widest xyzz image (BLS12-377 G2: 96 words)
+// staged host-to-device copies (dvn_h2d): ring of pinned chunks; DVN_H2D_BUFS is a multiple of the thread count
+constexpr int DVN_H2D_BUFS = 8, DVN_H2D_THREADS = 4;
+constexpr size_t DVN_H2D_CHUNK = (size_t)4 << 20, DVN_H2D_MIN = (size_t)16 << 20;
 
 struct dvn_ctx {
     int device = 0;
@@ -60,6 +63,13 @@ struct dvn_ctx {
     dvn_ctx* primary = nullptr;          // set in sub-contexts
     // sha256 -> proving key loaded from an artifact file (dvn_groth16_pk_load_file); keys stay owned by the cache
     std::vector<std::pair<std::string, struct dvn_groth16_pk*>> key_cache;
+    // large caller buffers (a witness, a scalar vector: pageable memory of the Go heap) go up through a ring of pinned chunks that
+    // a few host threads fill and DMA drains on a stream of its own (dvn_h2d, dvn_core.hip); created at the first large copy
+    void* h2d_pinned[DVN_H2D_BUFS] = {};
+    hipEvent_t h2d_done[DVN_H2D_BUFS] = {};
+    hipStream_t h2d_stream = nullptr;
+    hipEvent_t h2d_ev = nullptr;
+    int h2d_state = 0;                   // 0 = not set up yet, 1 = ready, -1 = unavailable (DVN_H2D_STAGED=0 or no pinned memory)
 };
 struct dvn_points {
     int suite = 0;            // 0 = BN254, 1 = BLS12-377
@@ -125,6 +135,14 @@ struct RoctxRange {
         }                                                                                                     \
     } while (0)
 #define TRY(expr) do { int32_t _rc = (expr); if (_rc != DVN_OK) return _rc; } while (0)
+
+// Host memory -> device memory, ordered on `consumer`: what `consumer` has queued before the call is finished before dst is
+// written, what it queues afterwards sees the data.  Returns when the caller's buffer has been READ completely (it may be
+// freed or reused: the cgo rule), not when the data has arrived.  Buffers of DVN_H2D_MIN bytes and more are staged through
+// pinned chunks by DVN_H2D_THREADS host threads (measured on the MI355X box: pageable hipMemcpy 30 GB/s, pinned DMA 57 GB/s,
+// a host copy on four threads 50 GB/s); smaller ones and a context without pinned memory take hipMemcpyAsync.
+// The caller holds ctx->mu (one staged copy per context at a time).
+int32_t dvn_h2d(dvn_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t consumer);
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

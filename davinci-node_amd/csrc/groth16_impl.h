@@ -538,7 +538,8 @@ template <class SU> static int32_t groth16_device(dvn_ctx* ctx, dvn_groth16_pk* 
         HIP_TRY(hipEventRecord(e0, st));
         if (!(flags & 2)) {    // flags & 2: the (completed) witness already sits in pk->d_w (committed proofs)
             RoctxRange rr("dvn:witness_copy");
-            HIP_TRY(hipMemcpyAsync(pk->d_w, witness, m * EB, (flags & 1) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+            if (flags & 1) HIP_TRY(hipMemcpyAsync(pk->d_w, witness, m * EB, hipMemcpyDeviceToDevice, st));
+            else TRY(dvn_h2d(ctx, pk->d_w, witness, m * EB, st));
             if (!(flags & 1)) pk->h2d_bytes += m * EB;
         }
         // (4) filter the wire vector by InfinityA / InfinityB
@@ -559,6 +560,8 @@ template <class SU> static int32_t groth16_device(dvn_ctx* ctx, dvn_groth16_pk* 
             if (abc_host) {                                    // the solver's (a, b, c) from host memory: their upload runs under the wire-only MSMs
                 RoctxRange rr("dvn:abc_copy");
                 for (int q = 0; q < 3; ++q) {
+                    // plain copies: these run beside the accumulate kernels of the wire-only MSMs, where the staged path (dvn_h2d) measured
+                    // 0.7 ms SLOWER per proof than the runtime's own pageable copy; it pays only while the GPU is otherwise idle
                     if (abc_len) HIP_TRY(hipMemcpyAsync(pk->d_abc + (size_t)q * n * EW, abc_host[q], abc_len * EB, hipMemcpyHostToDevice, st));
                     TRY(dvn_zero_async(pk->d_abc + ((size_t)q * n + abc_len) * EW, (n - abc_len) * EB, st));      // zero padding to the domain size
                 }

@@ -261,7 +261,7 @@ static int32_t msm_windows_staged(dvn_ctx* ctx, MsmLane& L, const dvn_points* pt
     const u32* d_scalars;
     if (!on_dev) {
         u32* tmp = cv.take<u32>(n * (SB / 4));
-        HIP_TRY(hipMemcpy(tmp, scalars, n * SB, hipMemcpyHostToDevice));   // caller's buffer is free on return (cgo rule)
+        TRY(dvn_h2d(ctx, tmp, scalars, n * SB, L.stream));                 // caller's buffer is free on return (cgo rule)
         d_scalars = tmp;
     } else d_scalars = (const u32*)scalars;
     int16_t* digits = cv.take<int16_t>(total);
@@ -420,7 +420,7 @@ static int32_t msm_expanded(dvn_ctx* ctx, MsmLane& L, const dvn_points* pts, siz
     const u32* d_scalars;
     if (!on_dev) {
         u32* tmp = cv.take<u32>(n * (SB / 4));
-        HIP_TRY(hipMemcpy(tmp, scalars, n * SB, hipMemcpyHostToDevice));   // caller's buffer is free on return (cgo rule)
+        TRY(dvn_h2d(ctx, tmp, scalars, n * SB, L.stream));                 // caller's buffer is free on return (cgo rule)
         d_scalars = tmp;
     } else d_scalars = (const u32*)scalars;
     int* digits = cv.take<int>(total);

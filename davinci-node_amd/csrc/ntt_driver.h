@@ -222,9 +222,11 @@ template <class S> static int32_t compute_h_api(dvn_ctx* ctx, const char* name, 
     TRY(ensure_ws(ctx, 3 * n * EB + 1024));
     u32* da = (u32*)ctx->ws; u32* db = da + n * S::EW; u32* dc = db + n * S::EW;
     hipStream_t st = ctx->stream;
-    HIP_TRY(hipMemcpyAsync(da, a, len * EB, in_kind, st));
-    HIP_TRY(hipMemcpyAsync(db, b, len * EB, in_kind, st));
-    HIP_TRY(hipMemcpyAsync(dc, c, len * EB, in_kind, st));
+    const uint64_t* in[3] = {a, b, c}; u32* dv[3] = {da, db, dc};
+    for (int q = 0; q < 3; ++q) {
+        if (on_dev) HIP_TRY(hipMemcpyAsync(dv[q], in[q], len * EB, in_kind, st));
+        else TRY(dvn_h2d(ctx, dv[q], in[q], len * EB, st));
+    }
     for (u32* v : {da, db, dc}) TRY(dvn_zero_async(v + len * S::EW, (n - len) * EB, st));          // zero padding to the domain size
     HIP_TRY(hipEventRecord(ctx->ev[0], st));
     TRY(compute_h_device<S>(ctx, dom, da, db, dc));

@@ -441,3 +441,23 @@ def test_outstanding_tickets_make_synchronous_calls_fail_cleanly(ctx, orc, pkg):
         again = key.prove(w, r, s)
         assert all((again[k] == proof[k]).all() for k in proof)
     key.free(); cs.free(); pts.free()
+
+
+@pytest.mark.gpu
+def test_host_scalars_through_the_staged_upload(ctx, orc):
+    """Scalar vectors of 16 MiB and more leave host memory through the ring of pinned chunks (four filler threads, own copy
+    stream): sizes just below and above the threshold, not a multiple of the chunk, several calls in a row (the ring is reused,
+    also while its last chunks of the call before may still be in flight) -- always the result of the device-resident vector."""
+    n_max = (1 << 20) + 12345                                             # 32 MiB + a ragged tail
+    pts = ctx.synthetic_g1(0xDA71C1, n_max)
+    d = ctx.synthetic_scalars(21, 0, n_max)
+    host = np.empty((n_max, 4), dtype=np.uint64); ctx.d2h(host, d)
+    for n in ((1 << 19) - 1, (1 << 19) + 3, n_max, (1 << 19) + 3, n_max):
+        want = ctx.msm_g1(pts, d, n=n)
+        got = ctx.msm_g1(pts, np.ascontiguousarray(host[:n]))
+        assert (got == want).all(), n
+    t = [ctx.msm_g1_submit(pts, np.ascontiguousarray(host[:n_max])) for _ in range(3)]     # three uploads back to back, three lanes
+    want = ctx.msm_g1(pts, d, n=n_max)
+    for k in t:
+        assert (ctx.msm_g1_collect(k) == want).all()
+    ctx.free(d); pts.free()
