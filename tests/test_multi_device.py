@@ -95,7 +95,7 @@ def test_one_msm_over_the_devices_of_a_context(pkg):
     test_gpu_parity.py); an expanded set (every device runs a real entry range) and a plain one (device 0 computes it whole)."""
     mc = pkg.Context([0, 0, 0])
     devs = [mc.device(i) for i in range(3)]
-    for n, kind in ((70001, 0), (40000, 1), (900, 0)):
+    for n, kind in ((70001, 0), (40000, 1), (900, 0), ((1 << 19) + 77, 0)):      # the last one: 16 MiB of host scalars, staged upload on every device at once
         sets = [d.synthetic_g1(0xDA71C1, n) for d in devs]
         ds = devs[0].synthetic_scalars(77, kind, n)
         sc = np.empty((n, 4), dtype=np.uint64); devs[0].d2h(sc, ds)
