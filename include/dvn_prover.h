@@ -101,7 +101,11 @@ int32_t dvn_points_free(dvn_ctx* ctx, dvn_points* pts);
 /* result = sum_{i<n} scalars[i] * points[off+i].  scalars_mont: n x 4 uint64 on the HOST.
  * out_jac: a valid Jacobian representative (this library returns the affine normal form with Z = 1, or
  * (1,1,0) for infinity); parity with gnark is defined after affine normalisation.
- * flags: DVN_MSM_* bits. */
+ * flags: DVN_MSM_* bits.
+ * Host buffers of 16 MiB and more (a scalar vector here, the witness of a proof) are read through a ring of pinned chunks
+ * that the context allocates at its first large copy (32 MiB of pinned host memory per context, freed by dvn_shutdown) and
+ * that four short-lived host threads fill: the caller's memory is never pinned and is free when the call returns.
+ * DVN_H2D_STAGED=0 in the environment keeps the plain copy. */
 #define DVN_MSM_DEFAULT 0u
 #define DVN_MSM_SCALARS_ON_DEVICE 1u   /* scalars_mont is a device pointer (HBM-resident witness) */
 int32_t dvn_msm_g1(dvn_ctx* ctx, const dvn_points* pts, size_t off, size_t n, const uint64_t* scalars_mont,
